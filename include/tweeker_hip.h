@@ -1,0 +1,276 @@
+/*
+ * tweeker_hip.h — C ABI of the MI355X-native path-tracing hot path.
+ *
+ * This is the drop-in seam that stands where rtigo3 talks to libnvoptix.so.1:
+ *   - the run-time loaded OptiX function table      (reference apps/rtigo3/src/Device.cpp:504-536)
+ *   - the per-GPU `Device` object wrapping it       (reference apps/rtigo3/inc/Device.h:292-404)
+ * Everything is plain C: opaque handle, POD structs, pointers and sizes. No C++/torch types.
+ * Every call returns 0 on success or a TwkResult error code; twk_last_error() returns the text
+ * (≙ OptixResult/CUresult + CheckMacros.h:38-80 which throw std::runtime_error; a C ABI never throws).
+ *
+ * A handle is NOT thread safe; one handle per GPU; all work of a handle is enqueued on its own
+ * non-blocking HIP stream (≙ Device.cpp:255) and calls of different handles may be interleaved
+ * from one host thread.
+ *
+ * The library never computes on the CPU: without a usable HIP device every compute entry point
+ * fails with TWK_ERROR_NO_DEVICE.
+ */
+#ifndef TWEEKER_HIP_H
+#define TWEEKER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWK_ABI_VERSION 1
+
+typedef enum TwkResult
+{
+  TWK_SUCCESS              = 0,
+  TWK_ERROR_INVALID_VALUE  = 1,
+  TWK_ERROR_NO_DEVICE      = 2, /* no HIP device / HIP runtime failure at create */
+  TWK_ERROR_HIP            = 3, /* a HIP call failed, text in twk_last_error() */
+  TWK_ERROR_INVALID_STATE  = 4, /* call order violated (e.g. launch before build) */
+  TWK_ERROR_OUT_OF_MEMORY  = 5,
+  TWK_ERROR_IO             = 6, /* scene/system description file problems */
+  TWK_ERROR_PARSE          = 7
+} TwkResult;
+
+/* ---- POD layouts shared with the reference (sizes asserted in the implementation) ---------- */
+
+/* ≙ CameraDefinition, reference shaders/camera_definition.h:34-40 (48 B) */
+typedef struct TwkCameraDefinition
+{
+  float P[3];
+  float U[3];
+  float V[3];
+  float W[3];
+} TwkCameraDefinition;
+
+/* ≙ LightType, reference shaders/light_definition.h:34-40 */
+enum { TWK_LIGHT_ENVIRONMENT = 0, TWK_LIGHT_PARALLELOGRAM = 1 };
+
+/* ≙ LightDefinition, reference shaders/light_definition.h:42-59 (80 B) */
+typedef struct TwkLightDefinition
+{
+  int   type;
+  float position[3];
+  float vecU[3];
+  float vecV[3];
+  float normal[3];
+  float area;
+  float emission[3];
+  float unused0, unused1, unused2;
+} TwkLightDefinition;
+
+/* ≙ FunctionIndex, reference shaders/function_indices.h:51-60 */
+enum
+{
+  TWK_INDEX_BRDF_DIFFUSE   = 0,
+  TWK_INDEX_BRDF_SPECULAR  = 1,
+  TWK_INDEX_BSDF_SPECULAR  = 2,
+  TWK_INDEX_BRDF_GGX_SMITH = 3,
+  TWK_INDEX_BSDF_GGX_SMITH = 4
+};
+
+/* ≙ LensShader, reference shaders/function_indices.h:42-49 */
+enum { TWK_LENS_SHADER_PINHOLE = 0, TWK_LENS_SHADER_FISHEYE = 1, TWK_LENS_SHADER_SPHERE = 2 };
+
+/* ≙ MaterialGUI without the name, reference inc/MaterialGUI.h:39-52. The device-side
+ * MaterialDefinition (absorption coefficient, FLAG_THINWALLED) is derived inside
+ * twk_init_materials exactly as Device::initMaterials does (Device.cpp:1022-1050). */
+typedef struct TwkMaterialGUI
+{
+  int   indexBSDF;
+  float albedo[3];
+  float absorptionColor[3];
+  float absorptionScale;
+  float ior;
+  int   thinwalled;
+  int   useAlbedoTexture;
+  int   useCutoutTexture;
+  float roughness[2];
+} TwkMaterialGUI;
+
+/* ≙ TriangleAttributes, reference shaders/vertex_attributes.h:34-40 (48 B) */
+typedef struct TwkTriangleAttributes
+{
+  float vertex[3];
+  float tangent[3];
+  float normal[3];
+  float texcoord[3];
+} TwkTriangleAttributes;
+
+/* ≙ DeviceState, reference inc/Device.h:277-290 */
+typedef struct TwkDeviceState
+{
+  int   resolution[2];
+  int   tileSize[2];     /* power of two */
+  int   pathLengths[2];  /* .x = min length before Russian roulette, .y = max length */
+  int   distribution;    /* 1: checkerboard tile distribution over deviceCount devices */
+  int   samplesSqrt;
+  int   lensShader;
+  float epsilonFactor;   /* sceneEpsilon = epsilonFactor * 1e-7 (config.h:42) */
+  float envRotation;
+  float clockFactor;     /* accepted, unused (USE_TIME_VIEW is 0 in the reference build) */
+} TwkDeviceState;
+
+/* Texture slots ≙ the three hard-wired textures of Device::initTextures (Device.cpp:911-942). */
+enum { TWK_TEXTURE_ALBEDO = 0, TWK_TEXTURE_CUTOUT = 1, TWK_TEXTURE_ENVIRONMENT = 2 };
+
+/* Per-launch work counters (device side, exact integers). */
+typedef struct TwkLaunchStats
+{
+  uint64_t radianceRays;    /* closest-hit rays traced */
+  uint64_t shadowRays;      /* any-hit rays traced */
+  uint64_t nodesVisited;    /* BVH2 nodes fetched (64 B each), both ray kinds */
+  uint64_t trianglesTested; /* triangle records fetched (48 B each) */
+  uint64_t instancesEntered;
+  uint64_t shadedHits;
+  uint64_t missed;
+} TwkLaunchStats;
+
+/* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */
+enum
+{
+  TWK_KERNEL_GENERATE = 0,
+  TWK_KERNEL_TRACE    = 1,
+  TWK_KERNEL_SHADE    = 2,
+  TWK_KERNEL_ACCUM    = 3,
+  TWK_KERNEL_COUNT    = 4
+};
+
+typedef struct TwkDevice_t* TwkDevice;
+
+/* ---- seam 1/2: the per-GPU renderer ------------------------------------------------------- */
+
+const char* twk_last_error(void);
+int twk_abi_version(void);
+int twk_device_count(int* count);
+
+/* ≙ Device::Device(strategy, ordinal, index, count, miss, ...) — Device.cpp:222-317.
+ * ordinal: HIP device ordinal. index/count: position in the set of rendering devices
+ * (tile distribution). miss: 0 = black, 1 = constant white env, 2 = spherical HDR env
+ * (selects the miss program like Device.cpp:660-672). */
+int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int miss);
+int twk_device_destroy(TwkDevice dev); /* ≙ Device::~Device, Device.cpp:320-358 */
+
+int twk_set_state(TwkDevice dev, const TwkDeviceState* state);                  /* ≙ Device::setState      Device.cpp:1192-1256 */
+int twk_init_cameras(TwkDevice dev, const TwkCameraDefinition* c, int count);   /* ≙ Device::initCameras   Device.cpp:944-968 */
+int twk_init_lights(TwkDevice dev, const TwkLightDefinition* l, int count);     /* ≙ Device::initLights    Device.cpp:970-1000 */
+int twk_init_materials(TwkDevice dev, const TwkMaterialGUI* m, int count);      /* ≙ Device::initMaterials Device.cpp:1002-1056 */
+int twk_update_camera(TwkDevice dev, int idCamera, const TwkCameraDefinition* c);   /* ≙ Device::updateCamera   Device.cpp:1083-1096 */
+int twk_update_light(TwkDevice dev, int idLight, const TwkLightDefinition* l);      /* ≙ Device::updateLight    Device.cpp:1098-1110 */
+int twk_update_material(TwkDevice dev, int idMaterial, const TwkMaterialGUI* m);    /* ≙ Device::updateMaterial Device.cpp:1112-1168 */
+
+/* ≙ Device::initTextures (Device.cpp:911-942). Texels are RGBA32F, row 0 = v 0 (origin lower left),
+ * bilinear, normalized coordinates; wrap in u and v except the environment which clamps v
+ * (Texture.cpp:668-693,1353). For TWK_TEXTURE_ENVIRONMENT the spherical CDFs and the integral
+ * are computed like Texture::calculateSphericalCDF (Texture.cpp:1500-1645). */
+int twk_init_texture(TwkDevice dev, int slot, const float* rgba, int width, int height);
+
+/* Scene ≙ Device::initScene → traverseNode (Device.cpp:1058-1080,1283-1331), flattened by the caller. */
+int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, size_t numAttributes,
+                     const unsigned int* indices, size_t numIndices, int* idGeometry); /* ≙ createGeometry (GAS) Device.cpp:1333-1425 */
+int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12],
+                     int idMaterial, int idLight, int* idInstance);                    /* ≙ createInstance Device.cpp:1427-1445 + hit record :1492-1532 */
+int twk_build(TwkDevice dev);                                                          /* ≙ createTLAS + createHitGroupRecords Device.cpp:1448-1532 */
+int twk_clear_scene(TwkDevice dev);
+
+/* ≙ Device*::render(iterationIndex, buffer) → optixLaunch(pipeline, stream, d_sys, 192, &sbt, W, H, 1)
+ * (DeviceSingleGPU.cpp:104-182; multi-GPU: DeviceMultiGPULocalCopy.cpp:104-190).
+ * Asynchronous on the handle's stream. One call = one sample per pixel of this device's share:
+ * the full W×H frame (distribution 0) or the launchWidth×H checkerboard tile set (distribution 1,
+ * raygeneration.cu:152-164,259-344). The accumulation buffer holds the running mean
+ * (raygeneration.cu:246-253), RGBA32F, alpha 1. */
+int twk_launch(TwkDevice dev, unsigned int iterationIndex);
+int twk_sync(TwkDevice dev);                                  /* ≙ Device::synchronizeStream */
+
+/* Output. With distribution 0 the buffer is W×H (≙ outputBuffer); with distribution 1 it is the
+ * packed launchWidth×H local tile buffer (≙ texelBuffer, DeviceMultiGPULocalCopy.cpp:109-172). */
+int twk_get_launch_width(TwkDevice dev, int* launchWidth);    /* ≙ m_launchWidth, DeviceMultiGPULocalCopy.cpp:84-97 */
+int twk_read_output(TwkDevice dev, float* rgbaHost, size_t numFloats); /* ≙ getOutputBufferHost, sync D2H */
+int twk_get_output_device_pointer(TwkDevice dev, void** dptr, size_t* bytes);
+/* Let the caller own the accumulation buffer (device memory of ≥ launchWidth*H*16 B, e.g. a
+ * torch tensor used as RCCL send buffer). Pass NULL to return to the internal buffer. */
+int twk_set_output_device_pointer(TwkDevice dev, void* dptr, size_t bytes);
+
+/* ≙ DeviceMultiGPULocalCopy::compositor + compositor.cu:38-64, for all source devices in one kernel:
+ * `tiles` is the gathered [deviceCount][H][launchWidth] RGBA32F block (device memory, rank order),
+ * `output` the full W×H RGBA32F image (device memory). Runs on this handle's stream. */
+int twk_compositor(TwkDevice dev, const void* tiles, void* output);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+int twk_profile_enable(TwkDevice dev, int enable);   /* hipEvent pair around every kernel launch */
+int twk_profile_reset(TwkDevice dev);
+int twk_profile_get(TwkDevice dev, float msPerKernelClass[TWK_KERNEL_COUNT], int launchesPerKernelClass[TWK_KERNEL_COUNT]);
+int twk_stats_enable(TwkDevice dev, int enable);     /* counting kernel variants (not for timed runs) */
+int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset);
+int twk_stream_peak_gbps(TwkDevice dev, size_t bytes, int repeats, float* gbps); /* float4 copy kernel */
+
+/* ---- debugging / parity taps (stage-level SoA read-back after one launch) ------------------ */
+/* First-bounce hit record per pixel of the last launch: t, beta, gamma, instance, primitive.
+ * Requires twk_debug_capture(dev, 1) before the launch. prim/inst = -1 on miss. */
+int twk_debug_capture(TwkDevice dev, int enable);
+int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma /*3 per px*/, int* instPrim /*2 per px*/, size_t numPixels);
+
+/* Closest-hit / any-hit query of arbitrary rays through the device BVH (≙ optixTrace contract,
+ * raygeneration.cu:84-89, closesthit.cu:281-286). rays: 8 floats each (o.xyz, tmin, d.xyz, tmax).
+ * out: t, beta, gamma per ray; ids: instance, primitive (or -1). anyHit != 0: ids[0] = 1 if occluded. */
+int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids);
+
+/* Unit taps of the device math used by the shaders (bit-exact parity with the oracle):
+ * op 0 sin, 1 cos, 2 exp, 3 atan2(x[i], y[i]), 4 acos, 5 atan, 6 sqrt, 7 1/x. */
+int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n);
+
+/* ---- host scene layer (rtigo3 Application: description files, meshes, camera) -------------- */
+typedef struct TwkApp_t* TwkApp;
+
+/* ≙ Application::loadSystemDescription (Application.cpp:1046-1299) + createCameras/createLights
+ * (:562-677) + loadSceneDescription (:1397-1878). */
+int twk_app_create(TwkApp* out, const char* systemDescriptionFile, const char* sceneDescriptionFile);
+int twk_app_create_from_strings(TwkApp* out, const char* systemDescription, const char* sceneDescription);
+int twk_app_destroy(TwkApp app);
+
+typedef struct TwkAppInfo
+{
+  int   strategy, devicesMask, light, miss, lensShader, samplesSqrt;
+  int   resolution[2], tileSize[2], pathLengths[2];
+  float epsilonFactor, envRotation, clockFactor;
+  float center[3], phi, theta, fov, distance;
+  int   numCameras, numLights, numMaterials, numGeometries, numInstances;
+} TwkAppInfo;
+
+int twk_app_info(TwkApp app, TwkAppInfo* info);
+int twk_app_set_resolution(TwkApp app, int width, int height); /* re-derives the camera frustum (aspect) */
+int twk_app_get_state(TwkApp app, TwkDeviceState* state);
+int twk_app_get_cameras(TwkApp app, TwkCameraDefinition* out, int capacity);
+int twk_app_get_lights(TwkApp app, TwkLightDefinition* out, int capacity);
+int twk_app_get_materials(TwkApp app, TwkMaterialGUI* out, int capacity);
+int twk_app_get_geometry_sizes(TwkApp app, int idGeometry, size_t* numAttributes, size_t* numIndices);
+int twk_app_get_geometry(TwkApp app, int idGeometry, TwkTriangleAttributes* attributes, unsigned int* indices);
+/* Flattened instance list in traverseNode order (Device.cpp:1283-1331). */
+int twk_app_get_instance(TwkApp app, int idInstance, int* idGeometry, float transform[12], int* idMaterial, int* idLight);
+/* Runs the reference's init sequence on a device: setState, initCameras, initLights, initMaterials,
+ * initScene (Application.cpp:303,328-332). */
+int twk_app_init_device(TwkApp app, TwkDevice dev);
+
+/* Stand-alone host helpers (≙ sg::Triangles::create*, Camera::getFrustum, calculateTileShift). */
+int twk_mesh_plane(unsigned int tessU, unsigned int tessV, unsigned int upAxis, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx);
+int twk_mesh_box(TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx);
+int twk_mesh_sphere(unsigned int tessU, unsigned int tessV, float radius, float maxTheta, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx);
+int twk_mesh_torus(unsigned int tessU, unsigned int tessV, float innerRadius, float outerRadius, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx);
+int twk_mesh_parallelogram(const float position[3], const float vecU[3], const float vecV[3], const float normal[3], TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx);
+int twk_camera_frustum(const float center[3], float phi, float theta, float fov, float distance, float aspect, TwkCameraDefinition* out); /* ≙ Camera::getFrustum Camera.cpp:187-216 */
+/* Tile map ≙ distribute() raygeneration.cu:152-164: launch column → pixel column. */
+int twk_tile_column(int launchX, int launchY, const int tileSize[2], int deviceCount, int deviceIndex, int* pixelX);
+int twk_launch_width(int width, int tileSizeX, int deviceCount, int* launchWidth); /* ≙ DeviceMultiGPULocalCopy.cpp:84-97 */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TWEEKER_HIP_H */

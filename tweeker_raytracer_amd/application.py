@@ -1,0 +1,143 @@
+"""Application — Python mirror of the scene-building half of rtigo3's `Application`
+(reference src/Application.cpp: loadSystemDescription :1046-1299, createLights :572-677,
+loadSceneDescription :1397-1878). Parsing, mesh generation and flattening run in C++ inside
+libtweeker_hip.so; this class only exposes the result.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Application:
+    def __init__(self, system_file=None, scene_file=None, system_text=None, scene_text=None):
+        self._h = C.c_void_p()
+        if system_text is not None or scene_text is not None:
+            L.check(L.lib.twk_app_create_from_strings(C.byref(self._h), (system_text or "").encode(), (scene_text or "").encode()))
+        else:
+            L.check(L.lib.twk_app_create(C.byref(self._h), str(system_file).encode(), str(scene_file).encode()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib.twk_app_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self):
+        i = L.AppInfo()
+        L.check(L.lib.twk_app_info(self._h, C.byref(i)))
+        return i
+
+    def setResolution(self, width, height):
+        L.check(L.lib.twk_app_set_resolution(self._h, int(width), int(height)))
+
+    @property
+    def state(self):
+        s = L.DeviceState()
+        L.check(L.lib.twk_app_get_state(self._h, C.byref(s)))
+        return s
+
+    @property
+    def cameras(self):
+        n = self.info.numCameras
+        arr = (L.CameraDefinition * max(1, n))()
+        L.check(L.lib.twk_app_get_cameras(self._h, arr, n))
+        return list(arr)[:n]
+
+    @property
+    def lights(self):
+        n = self.info.numLights
+        arr = (L.LightDefinition * max(1, n))()
+        L.check(L.lib.twk_app_get_lights(self._h, arr, n))
+        return list(arr)[:n]
+
+    @property
+    def materials(self):
+        n = self.info.numMaterials
+        arr = (L.MaterialGUI * max(1, n))()
+        L.check(L.lib.twk_app_get_materials(self._h, arr, n))
+        return list(arr)[:n]
+
+    def geometry(self, idGeometry):
+        na, ni = C.c_size_t(0), C.c_size_t(0)
+        L.check(L.lib.twk_app_get_geometry_sizes(self._h, int(idGeometry), C.byref(na), C.byref(ni)))
+        attr = np.empty((na.value, 12), dtype=np.float32)
+        idx = np.empty((ni.value,), dtype=np.uint32)
+        L.check(L.lib.twk_app_get_geometry(self._h, int(idGeometry), attr.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p)))
+        return attr, idx
+
+    def instance(self, idInstance):
+        g, m, l = C.c_int(0), C.c_int(0), C.c_int(0)
+        t = (C.c_float * 12)()
+        L.check(L.lib.twk_app_get_instance(self._h, int(idInstance), C.byref(g), t, C.byref(m), C.byref(l)))
+        return g.value, np.array(list(t), dtype=np.float32), m.value, l.value
+
+    @property
+    def instances(self):
+        return [self.instance(i) for i in range(self.info.numInstances)]
+
+    def initDevice(self, device, distribution=None):
+        """≙ Application.cpp:303,328-332: initState, initCameras, initLights, initMaterials, initScene."""
+        L.check(L.lib.twk_app_init_device(self._h, device.handle))
+        st = self.state
+        if distribution is not None:
+            st.distribution = int(distribution)
+            device.setState(st)
+        else:
+            device.state = st
+
+
+def _mesh_call(fn, *args):
+    na, ni = C.c_size_t(0), C.c_size_t(0)
+    L.check(fn(*args, None, C.byref(na), None, C.byref(ni)))
+    attr = np.empty((na.value, 12), dtype=np.float32)
+    idx = np.empty((ni.value,), dtype=np.uint32)
+    L.check(fn(*args, attr.ctypes.data_as(C.c_void_p), C.byref(na), idx.ctypes.data_as(C.c_void_p), C.byref(ni)))
+    return attr, idx
+
+
+def mesh_plane(tessU, tessV, upAxis):
+    return _mesh_call(L.lib.twk_mesh_plane, C.c_uint(tessU), C.c_uint(tessV), C.c_uint(upAxis))
+
+
+def mesh_box():
+    return _mesh_call(L.lib.twk_mesh_box)
+
+
+def mesh_sphere(tessU, tessV, radius, maxTheta):
+    return _mesh_call(L.lib.twk_mesh_sphere, C.c_uint(tessU), C.c_uint(tessV), C.c_float(radius), C.c_float(maxTheta))
+
+
+def mesh_torus(tessU, tessV, innerRadius, outerRadius):
+    return _mesh_call(L.lib.twk_mesh_torus, C.c_uint(tessU), C.c_uint(tessV), C.c_float(innerRadius), C.c_float(outerRadius))
+
+
+def mesh_parallelogram(position, vecU, vecV, normal):
+    v = lambda a: (C.c_float * 3)(*[float(x) for x in a])
+    return _mesh_call(L.lib.twk_mesh_parallelogram, v(position), v(vecU), v(vecV), v(normal))
+
+
+def camera_frustum(center, phi, theta, fov, distance, aspect):
+    c = L.CameraDefinition()
+    L.check(L.lib.twk_camera_frustum((C.c_float * 3)(*center), C.c_float(phi), C.c_float(theta), C.c_float(fov),
+                                     C.c_float(distance), C.c_float(aspect), C.byref(c)))
+    return c
+
+
+def tile_column(launchX, launchY, tileSize, deviceCount, deviceIndex):
+    px = C.c_int(0)
+    L.check(L.lib.twk_tile_column(int(launchX), int(launchY), (C.c_int * 2)(*tileSize), int(deviceCount), int(deviceIndex), C.byref(px)))
+    return px.value
+
+
+def launch_width(width, tileSizeX, deviceCount):
+    w = C.c_int(0)
+    L.check(L.lib.twk_launch_width(int(width), int(tileSizeX), int(deviceCount), C.byref(w)))
+    return w.value

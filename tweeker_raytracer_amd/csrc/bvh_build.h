@@ -1,0 +1,37 @@
+#pragma once
+#include "device_types.h"
+
+namespace twk {
+
+// Scratch-owning LBVH builder, reused for every geometry (bottom level) and for the instance level.
+class BvhBuilder
+{
+public:
+  ~BvhBuilder() { release(); }
+
+  // Bottom level over the triangles of one geometry. Writes max(1, numTriangles - 1) nodes at
+  // outNodes[0..] whose inner references are nodeBase-relative absolutes and numTriangles triangle
+  // slots at outTriangles[3 * triangleBase ..]. rootBounds receives the (padded) object-space box.
+  hipError_t buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
+                            BvhNode* outNodes, int nodeBase, float4* outTriangles, int triangleBase, float rootBounds[6]);
+
+  // Top level over instance boxes given on the host. Leaf reference = ~instance index.
+  hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, int nodeBase);
+
+  void release();
+
+private:
+  hipError_t reserve(int count);
+  hipError_t buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, int nodeBase, int leafMode, int leafBase);
+
+  int m_capacity = 0;
+  float4* m_primLo = nullptr; float4* m_primHi = nullptr;
+  unsigned long long* m_keysIn = nullptr; unsigned long long* m_keysOut = nullptr;
+  int* m_left = nullptr; int* m_right = nullptr; int* m_innerParent = nullptr; int* m_leafParent = nullptr;
+  unsigned int* m_tickets = nullptr;
+  float4* m_nodeLo = nullptr; float4* m_nodeHi = nullptr;
+  unsigned int* m_bounds = nullptr;
+  void* m_sortTemp = nullptr; size_t m_sortBytes = 0;
+};
+
+} // namespace twk

@@ -1,0 +1,336 @@
+// On-device LBVH builder (stands where optixAccelBuild stood: GAS src/Device.cpp:1362-1407, IAS :1456-1486).
+//
+// Pipeline, all on the GPU: primitive boxes → 30-bit Morton code of the box centre → 64-bit key
+// (code << 32 | primitive index) → radix sort (rocPRIM) → Karras 2012 binary radix tree (one thread per
+// inner node) → bottom-up box refit with one atomic ticket per inner node → 64-byte BVH2 nodes that
+// store the boxes of both children (one node fetch decides both descents).
+// The same builder serves both levels: triangles of one geometry (bottom level, object space) and
+// instance boxes (top level, world space).
+#include "device_types.h"
+#include "bvh_build.h"
+
+#include <cstring>
+#include <cstdlib>
+#include <rocprim/rocprim.hpp>
+
+namespace twk {
+
+// Order-preserving float <-> uint mapping for atomicMin/atomicMax on floats.
+TWK_D unsigned int orderedBits(float f)
+{
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+TWK_D float fromOrderedBits(unsigned int u)
+{
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void initBoundsKernel(unsigned int* bounds)
+{
+  if (threadIdx.x < 3) bounds[threadIdx.x] = 0xffffffffu;      // min
+  else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;          // max
+}
+
+// Triangle boxes of one geometry. attributes: 12 floats per vertex (position first), indices: 3 per triangle.
+__global__ void triangleBoxesKernel(const float* __restrict__ attributes, const unsigned int* __restrict__ indices,
+                                    int count, float4* __restrict__ primLo, float4* __restrict__ primHi, unsigned int* bounds)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const unsigned int i0 = indices[3 * i], i1 = indices[3 * i + 1], i2 = indices[3 * i + 2];
+  const float* a = attributes + 12 * (size_t) i0;
+  const float* b = attributes + 12 * (size_t) i1;
+  const float* c = attributes + 12 * (size_t) i2;
+  float lo[3], hi[3];
+  for (int k = 0; k < 3; ++k)
+  {
+    lo[k] = fminf(fminf(a[k], b[k]), c[k]);
+    hi[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+  }
+  primLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+  primHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+  for (int k = 0; k < 3; ++k)
+  {
+    atomicMin(&bounds[k], orderedBits(lo[k]));
+    atomicMax(&bounds[3 + k], orderedBits(hi[k]));
+  }
+}
+
+__global__ void boxBoundsKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi, int count, unsigned int* bounds)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float4 lo = primLo[i], hi = primHi[i];
+  atomicMin(&bounds[0], orderedBits(lo.x)); atomicMin(&bounds[1], orderedBits(lo.y)); atomicMin(&bounds[2], orderedBits(lo.z));
+  atomicMax(&bounds[3], orderedBits(hi.x)); atomicMax(&bounds[4], orderedBits(hi.y)); atomicMax(&bounds[5], orderedBits(hi.z));
+}
+
+TWK_D unsigned int expandBits10(unsigned int v)
+{
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ void mortonKeysKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi, int count,
+                                 const unsigned int* __restrict__ bounds, unsigned long long* __restrict__ keys)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float4 lo = primLo[i], hi = primHi[i];
+  const float c[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
+  unsigned int q[3];
+  for (int k = 0; k < 3; ++k)
+  {
+    const float bl = fromOrderedBits(bounds[k]);
+    const float bh = fromOrderedBits(bounds[3 + k]);
+    const float ext = bh - bl;
+    float n = (ext > 0.0f) ? (c[k] - bl) / ext : 0.0f;
+    n = fminf(fmaxf(n * 1024.0f, 0.0f), 1023.0f);
+    q[k] = (unsigned int) n;
+  }
+  const unsigned int code = (expandBits10(q[0]) << 2) | (expandBits10(q[1]) << 1) | expandBits10(q[2]);
+  keys[i] = ((unsigned long long) code << 32) | (unsigned int) i;
+}
+
+// Length of the common prefix of keys i and j, -1 when j is out of range (Karras 2012, section 4).
+TWK_D int commonPrefix(const unsigned long long* __restrict__ keys, int count, int i, int j)
+{
+  if (j < 0 || j >= count) return -1;
+  return __clzll((long long) (keys[i] ^ keys[j])); // keys are unique (index in the low word)
+}
+
+// One thread per inner node. childRef encoding while building: >= 0 inner node, < 0 leaf ~position.
+__global__ void radixTreeKernel(const unsigned long long* __restrict__ keys, int count,
+                                int* __restrict__ left, int* __restrict__ right,
+                                int* __restrict__ innerParent, int* __restrict__ leafParent)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count - 1) return;
+
+  const int d = (commonPrefix(keys, count, i, i + 1) - commonPrefix(keys, count, i, i - 1)) >= 0 ? 1 : -1;
+  const int deltaMin = commonPrefix(keys, count, i, i - d);
+  int lmax = 2;
+  while (commonPrefix(keys, count, i, i + lmax * d) > deltaMin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+  {
+    if (commonPrefix(keys, count, i, i + (l + t) * d) > deltaMin) l += t;
+  }
+  const int j = i + l * d;
+  const int deltaNode = commonPrefix(keys, count, i, j);
+  int s = 0;
+  int t = l;
+  do
+  {
+    t = (t + 1) >> 1;
+    if (commonPrefix(keys, count, i, i + (s + t) * d) > deltaNode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+
+  const int lo = min(i, j), hi = max(i, j);
+  const int leftRef  = (lo == gamma)     ? ~gamma       : gamma;
+  const int rightRef = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  left[i]  = leftRef;
+  right[i] = rightRef;
+  if (leftRef  >= 0) innerParent[leftRef]  = i; else leafParent[~leftRef]  = i;
+  if (rightRef >= 0) innerParent[rightRef] = i; else leafParent[~rightRef] = i;
+  if (i == 0) innerParent[0] = -1;
+}
+
+TWK_D void padBox(float4& lo, float4& hi)
+{
+  // The watertight triangle test may accept a ray that misses the exact triangle by a rounding error;
+  // boxes are grown so the conservative slab test never culls such a hit.
+  const float k = 1.9073486e-6f; // 2^-19
+  const float ex = k * (fmaxf(fabsf(lo.x), fabsf(hi.x)) + (hi.x - lo.x)) + 1.0e-30f;
+  const float ey = k * (fmaxf(fabsf(lo.y), fabsf(hi.y)) + (hi.y - lo.y)) + 1.0e-30f;
+  const float ez = k * (fmaxf(fabsf(lo.z), fabsf(hi.z)) + (hi.z - lo.z)) + 1.0e-30f;
+  lo.x -= ex; lo.y -= ey; lo.z -= ez;
+  hi.x += ex; hi.y += ey; hi.z += ez;
+}
+
+TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const float4& lo1, const float4& hi1, int c0, int c1)
+{
+  float4* p = reinterpret_cast<float4*>(node);
+  p[0] = make_float4(lo0.x, lo0.y, lo0.z, hi0.x);
+  p[1] = make_float4(hi0.y, hi0.z, lo1.x, lo1.y);
+  p[2] = make_float4(lo1.z, hi1.x, hi1.y, hi1.z);
+  p[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
+}
+
+// One thread per leaf walks up; the second thread to arrive at an inner node (ticket == 1) owns it.
+// leafMode 0: leaf reference = ~(leafBase + sorted position); 1: leaf reference = ~(primitive index).
+__global__ void refitKernel(const unsigned long long* __restrict__ keys, int count,
+                            const float4* __restrict__ primLo, const float4* __restrict__ primHi,
+                            const int* __restrict__ left, const int* __restrict__ right,
+                            const int* __restrict__ innerParent, const int* __restrict__ leafParent,
+                            unsigned int* __restrict__ tickets, float4* nodeLo, float4* nodeHi,
+                            BvhNode* __restrict__ outNodes, int nodeBase, int leafMode, int leafBase)
+{
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= count) return;
+
+  int node = leafParent[leaf];
+  while (node >= 0)
+  {
+    __threadfence();
+    const unsigned int ticket = atomicAdd(&tickets[node], 1u);
+    if (ticket == 0) return; // the sibling subtree is not finished; its thread will continue
+    __threadfence();
+
+    const int l = left[node], r = right[node];
+    float4 lo0, hi0, lo1, hi1;
+    int c0, c1;
+    if (l < 0)
+    {
+      const unsigned int prim = (unsigned int) (keys[~l] & 0xffffffffull);
+      lo0 = primLo[prim]; hi0 = primHi[prim]; padBox(lo0, hi0);
+      c0 = (leafMode == 0) ? ~(leafBase + ~l) : ~((int) prim);
+    }
+    else
+    {
+      lo0 = nodeLo[l]; hi0 = nodeHi[l];
+      c0 = nodeBase + l;
+    }
+    if (r < 0)
+    {
+      const unsigned int prim = (unsigned int) (keys[~r] & 0xffffffffull);
+      lo1 = primLo[prim]; hi1 = primHi[prim]; padBox(lo1, hi1);
+      c1 = (leafMode == 0) ? ~(leafBase + ~r) : ~((int) prim);
+    }
+    else
+    {
+      lo1 = nodeLo[r]; hi1 = nodeHi[r];
+      c1 = nodeBase + r;
+    }
+    writeNode(&outNodes[node], lo0, hi0, lo1, hi1, c0, c1);
+    nodeLo[node] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
+    nodeHi[node] = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
+    node = innerParent[node];
+  }
+}
+
+// A single primitive has no inner node: emit one node whose second child can never be hit.
+__global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi,
+                                 BvhNode* outNodes, float4* nodeLo, float4* nodeHi, int leafMode, int leafBase)
+{
+  float4 lo = primLo[0], hi = primHi[0];
+  padBox(lo, hi);
+  const float inf = __uint_as_float(0x7f800000u);
+  const float4 elo = make_float4(inf, inf, inf, 0.0f), ehi = make_float4(-inf, -inf, -inf, 0.0f);
+  writeNode(&outNodes[0], lo, hi, elo, ehi, (leafMode == 0) ? ~leafBase : ~0, ~0);
+  nodeLo[0] = lo; nodeHi[0] = hi;
+}
+
+// Triangle slots in leaf order: three float4 per slot, w of the first = primitive index.
+__global__ void emitTrianglesKernel(const float* __restrict__ attributes, const unsigned int* __restrict__ indices,
+                                    const unsigned long long* __restrict__ keys, int count, float4* __restrict__ triangles)
+{
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= count) return;
+  const unsigned int prim = (unsigned int) (keys[slot] & 0xffffffffull);
+  const unsigned int i0 = indices[3 * prim], i1 = indices[3 * prim + 1], i2 = indices[3 * prim + 2];
+  const float* a = attributes + 12 * (size_t) i0;
+  const float* b = attributes + 12 * (size_t) i1;
+  const float* c = attributes + 12 * (size_t) i2;
+  triangles[3 * (size_t) slot + 0] = make_float4(a[0], a[1], a[2], __uint_as_float(prim));
+  triangles[3 * (size_t) slot + 1] = make_float4(b[0], b[1], b[2], 0.0f);
+  triangles[3 * (size_t) slot + 2] = make_float4(c[0], c[1], c[2], 0.0f);
+}
+
+#define BVH_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t BvhBuilder::reserve(int count)
+{
+  if (count <= m_capacity) return hipSuccess;
+  release();
+  const size_t n = (size_t) count;
+  BVH_CHECK(hipMalloc(&m_primLo, sizeof(float4) * n));
+  BVH_CHECK(hipMalloc(&m_primHi, sizeof(float4) * n));
+  BVH_CHECK(hipMalloc(&m_keysIn, sizeof(unsigned long long) * n));
+  BVH_CHECK(hipMalloc(&m_keysOut, sizeof(unsigned long long) * n));
+  BVH_CHECK(hipMalloc(&m_left, sizeof(int) * n));
+  BVH_CHECK(hipMalloc(&m_right, sizeof(int) * n));
+  BVH_CHECK(hipMalloc(&m_innerParent, sizeof(int) * n));
+  BVH_CHECK(hipMalloc(&m_leafParent, sizeof(int) * n));
+  BVH_CHECK(hipMalloc(&m_tickets, sizeof(unsigned int) * n));
+  BVH_CHECK(hipMalloc(&m_nodeLo, sizeof(float4) * n));
+  BVH_CHECK(hipMalloc(&m_nodeHi, sizeof(float4) * n));
+  BVH_CHECK(hipMalloc(&m_bounds, sizeof(unsigned int) * 8));
+  m_sortBytes = 0;
+  BVH_CHECK(rocprim::radix_sort_keys(nullptr, m_sortBytes, m_keysIn, m_keysOut, n, 0, 64, (hipStream_t) 0));
+  BVH_CHECK(hipMalloc(&m_sortTemp, m_sortBytes > 0 ? m_sortBytes : 16));
+  m_capacity = count;
+  return hipSuccess;
+}
+
+void BvhBuilder::release()
+{
+  void* p[] = { m_primLo, m_primHi, m_keysIn, m_keysOut, m_left, m_right, m_innerParent, m_leafParent, m_tickets, m_nodeLo, m_nodeHi, m_bounds, m_sortTemp };
+  for (void* q : p) if (q) (void) hipFree(q);
+  m_primLo = m_primHi = m_nodeLo = m_nodeHi = nullptr;
+  m_keysIn = m_keysOut = nullptr;
+  m_left = m_right = m_innerParent = m_leafParent = nullptr;
+  m_tickets = nullptr; m_bounds = nullptr; m_sortTemp = nullptr;
+  m_capacity = 0;
+}
+
+hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, int nodeBase, int leafMode, int leafBase)
+{
+  const int block = 256;
+  const int grid  = (count + block - 1) / block;
+  if (count == 1)
+  {
+    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, m_nodeLo, m_nodeHi, leafMode, leafBase);
+    // keysOut[0] must still name primitive 0 for emitTriangles
+    BVH_CHECK(hipMemsetAsync(m_keysOut, 0, sizeof(unsigned long long), stream));
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(mortonKeysKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, count, m_bounds, m_keysIn);
+  BVH_CHECK(rocprim::radix_sort_keys(m_sortTemp, m_sortBytes, m_keysIn, m_keysOut, (size_t) count, 0, 64, stream));
+  BVH_CHECK(hipMemsetAsync(m_tickets, 0, sizeof(unsigned int) * count, stream));
+  hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent);
+  hipLaunchKernelGGL(refitKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_primLo, m_primHi, m_left, m_right,
+                     m_innerParent, m_leafParent, m_tickets, m_nodeLo, m_nodeHi, outNodes, nodeBase, leafMode, leafBase);
+  return hipGetLastError();
+}
+
+hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
+                                      BvhNode* outNodes, int nodeBase, float4* outTriangles, int triangleBase, float rootBounds[6])
+{
+  BVH_CHECK(reserve(numTriangles));
+  const int block = 256;
+  const int grid  = (numTriangles + block - 1) / block;
+  hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
+  hipLaunchKernelGGL(triangleBoxesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, numTriangles, m_primLo, m_primHi, m_bounds);
+  BVH_CHECK(buildFromBoxes(stream, numTriangles, outNodes, nodeBase, 0, triangleBase));
+  hipLaunchKernelGGL(emitTrianglesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, m_keysOut, numTriangles, outTriangles + 3 * (size_t) triangleBase);
+  BVH_CHECK(hipGetLastError());
+  float4 lo, hi;
+  BVH_CHECK(hipMemcpyAsync(&lo, m_nodeLo, sizeof(float4), hipMemcpyDeviceToHost, stream));
+  BVH_CHECK(hipMemcpyAsync(&hi, m_nodeHi, sizeof(float4), hipMemcpyDeviceToHost, stream));
+  BVH_CHECK(hipStreamSynchronize(stream));
+  rootBounds[0] = lo.x; rootBounds[1] = lo.y; rootBounds[2] = lo.z;
+  rootBounds[3] = hi.x; rootBounds[4] = hi.y; rootBounds[5] = hi.z;
+  return hipSuccess;
+}
+
+hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, int nodeBase)
+{
+  BVH_CHECK(reserve(numInstances));
+  const int block = 256;
+  const int grid  = (numInstances + block - 1) / block;
+  BVH_CHECK(hipMemcpyAsync(m_primLo, hostLo, sizeof(float4) * numInstances, hipMemcpyHostToDevice, stream));
+  BVH_CHECK(hipMemcpyAsync(m_primHi, hostHi, sizeof(float4) * numInstances, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
+  hipLaunchKernelGGL(boxBoundsKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, numInstances, m_bounds);
+  BVH_CHECK(buildFromBoxes(stream, numInstances, outNodes, nodeBase, 1, 0));
+  BVH_CHECK(hipStreamSynchronize(stream)); // hostLo/hostHi may go away
+  return hipSuccess;
+}
+
+} // namespace twk

@@ -1,0 +1,924 @@
+// The per-GPU renderer behind the C ABI of include/tweeker_hip.h (≙ rtigo3's Device family,
+// reference apps/rtigo3/src/Device.cpp + DeviceSingleGPU.cpp + DeviceMultiGPULocalCopy.cpp).
+// Host code here only moves data and enqueues kernels; nothing is ever computed on the CPU in place
+// of a kernel. Without a HIP device every entry point that needs one fails.
+#include "device_types.h"
+#include "bvh_build.h"
+#include "error_state.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_lastError;
+
+int twkSetError(int code, const std::string& message)
+{
+  g_lastError = message;
+  return code;
+}
+
+namespace twk {
+void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream);
+void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream);
+void launchGenerate(const LaunchParams& p, hipStream_t stream);
+void launchShade(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream);
+void launchAccumulate(const LaunchParams& p, hipStream_t stream);
+void launchCompositor(const float4* tiles, float4* output, int width, int height, int launchWidth, int deviceCount,
+                      int tileSizeX, int tileShiftX, int tileShiftY, hipStream_t stream);
+void launchMathTap(int op, const float* x, const float* y, float* out, size_t n, hipStream_t stream);
+void launchStreamCopy(const float4* src, float4* dst, size_t n, hipStream_t stream);
+}
+
+using namespace twk;
+
+#define HIP_TRY(call)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return twkSetError((e_ == hipErrorOutOfMemory) ? TWK_ERROR_OUT_OF_MEMORY : TWK_ERROR_HIP,    \
+                         std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+static_assert(sizeof(TwkCameraDefinition) == 48, "CameraDefinition is 48 B (camera_definition.h:34-40)");
+static_assert(sizeof(TwkLightDefinition) == 80, "LightDefinition is 80 B (light_definition.h:42-59)");
+static_assert(sizeof(TwkTriangleAttributes) == 48, "TriangleAttributes is 48 B (vertex_attributes.h:34-40)");
+static_assert(sizeof(DevLight) == sizeof(TwkLightDefinition), "device light layout");
+static_assert(sizeof(DevMaterial) == 64, "MaterialDefinition is 64 B (material_definition.h:37-56)");
+static_assert(sizeof(DevInstance) == 128, "instance record");
+static_assert(sizeof(BvhNode) == 64, "BVH2 node");
+
+struct GeometryHost
+{
+  std::vector<TwkTriangleAttributes> attributes;
+  std::vector<unsigned int>          indices;
+  unsigned int attributeBase = 0, indexBase = 0;
+  int triangleBase = 0, nodeBase = 0, numTriangles = 0;
+  float rootBounds[6];
+};
+
+struct InstanceHost
+{
+  int   geometry;
+  float transform[12];
+  int   material, light;
+};
+
+struct TimedLaunch { hipEvent_t start, stop; int kind; };
+
+struct TwkDevice_t
+{
+  int ordinal = 0, index = 0, count = 1, miss = 1;
+  int numCUs = 256;
+  hipStream_t stream = nullptr;
+
+  TwkDeviceState state;
+  bool stateSet = false;
+  int  launchWidth = 1;
+
+  std::vector<TwkCameraDefinition> cameras;
+  std::vector<TwkLightDefinition>  lights;
+  std::vector<DevMaterial>         materials;
+  std::vector<GeometryHost>        geometries;
+  std::vector<InstanceHost>        instances;
+  bool built = false;
+
+  // device memory
+  float* d_camera = nullptr;
+  DevLight* d_lights = nullptr;
+  DevMaterial* d_materials = nullptr; int materialCapacity = 0;
+  float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
+  BvhNode* d_nodes = nullptr; float4* d_triangles = nullptr; DevInstance* d_instances = nullptr;
+  float4* d_texels[3] = {nullptr, nullptr, nullptr};
+  float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
+  int tlasRoot = 0;
+  size_t totalNodes = 0, totalTriangles = 0;
+
+  // per-resolution streams
+  int allocatedPixels = 0;
+  void* d_streamBlock = nullptr; // one allocation carved into the SoA streams
+  float4* d_outputInternal = nullptr;
+  float4* d_outputExternal = nullptr; size_t outputExternalBytes = 0;
+  unsigned int* d_counters = nullptr;
+  unsigned long long* d_stats = nullptr;
+  int* d_spill = nullptr; size_t spillLanes = 0;
+  float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
+  bool captureFirstHits = false;
+  bool statsEnabled = false;
+  bool profileEnabled = false;
+  std::vector<TimedLaunch> timed; size_t timedUsed = 0;
+  float profileMs[TWK_KERNEL_COUNT] = {0, 0, 0, 0};
+  int   profileLaunches[TWK_KERNEL_COUNT] = {0, 0, 0, 0};
+
+  LaunchParams params;
+  BvhBuilder builder;
+};
+
+static int activate(TwkDevice dev, const char* where)
+{
+  if (!dev) return twkSetError(TWK_ERROR_INVALID_VALUE, std::string(where) + ": NULL device handle");
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  return TWK_SUCCESS;
+}
+
+template<typename T> static void freeDevice(T*& p) { if (p) { (void) hipFree(p); p = nullptr; } }
+
+// Inverse of a row-major 3x4 affine matrix in double, rounded once (OptiX derives the same matrix for
+// optixGetInstanceInverseTransformFromHandle, closesthit.cu:49-52).
+static void invertAffine(const float m[12], float inv[12])
+{
+  const double a00 = m[0], a01 = m[1], a02 = m[2],  t0 = m[3];
+  const double a10 = m[4], a11 = m[5], a12 = m[6],  t1 = m[7];
+  const double a20 = m[8], a21 = m[9], a22 = m[10], t2 = m[11];
+  const double c00 = a11 * a22 - a12 * a21;
+  const double c01 = a12 * a20 - a10 * a22;
+  const double c02 = a10 * a21 - a11 * a20;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double r = 1.0 / det;
+  const double i00 = c00 * r, i01 = (a02 * a21 - a01 * a22) * r, i02 = (a01 * a12 - a02 * a11) * r;
+  const double i10 = c01 * r, i11 = (a00 * a22 - a02 * a20) * r, i12 = (a02 * a10 - a00 * a12) * r;
+  const double i20 = c02 * r, i21 = (a01 * a20 - a00 * a21) * r, i22 = (a00 * a11 - a01 * a10) * r;
+  inv[0] = (float) i00; inv[1] = (float) i01; inv[2]  = (float) i02; inv[3]  = (float) -(i00 * t0 + i01 * t1 + i02 * t2);
+  inv[4] = (float) i10; inv[5] = (float) i11; inv[6]  = (float) i12; inv[7]  = (float) -(i10 * t0 + i11 * t1 + i12 * t2);
+  inv[8] = (float) i20; inv[9] = (float) i21; inv[10] = (float) i22; inv[11] = (float) -(i20 * t0 + i21 * t1 + i22 * t2);
+}
+
+// MaterialGUI → MaterialDefinition, Device.cpp:1022-1050
+static DevMaterial convertMaterial(const TwkMaterialGUI& g)
+{
+  DevMaterial m;
+  memset(&m, 0, sizeof(m));
+  m.textureAlbedo = g.useAlbedoTexture ? (TWK_TEXTURE_ALBEDO + 1) : 0;
+  m.textureCutout = g.useCutoutTexture ? (TWK_TEXTURE_CUTOUT + 1) : 0;
+  m.roughness[0] = g.roughness[0]; m.roughness[1] = g.roughness[1];
+  m.indexBSDF = g.indexBSDF;
+  m.albedo[0] = g.albedo[0]; m.albedo[1] = g.albedo[1]; m.albedo[2] = g.albedo[2];
+  m.absorption[0] = m.absorption[1] = m.absorption[2] = 0.0f;
+  if (0.0f < g.absorptionScale)
+  {
+    const float x = -logf(fmax(0.0001f, g.absorptionColor[0]));
+    const float y = -logf(fmax(0.0001f, g.absorptionColor[1]));
+    const float z = -logf(fmax(0.0001f, g.absorptionColor[2]));
+    m.absorption[0] = x * g.absorptionScale; m.absorption[1] = y * g.absorptionScale; m.absorption[2] = z * g.absorptionScale;
+  }
+  m.ior   = g.ior;
+  m.flags = g.thinwalled ? TWK_FLAG_THINWALLED : 0u;
+  return m;
+}
+
+static int calculateShift(int size) // Device.cpp:1172-1189
+{
+  int s = 0;
+  while (s < 32 && (size & (1 << s)) == 0) ++s;
+  return s;
+}
+
+static void refreshParams(TwkDevice dev)
+{
+  LaunchParams& p = dev->params;
+  p.nodes = dev->d_nodes; p.triangles = dev->d_triangles; p.instances = dev->d_instances;
+  p.attributes = dev->d_attributes; p.indices = dev->d_indices;
+  p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
+  p.tlasRoot = dev->tlasRoot;
+  p.numInstances = (int) dev->instances.size();
+  p.numLights = (int) dev->lights.size();
+  p.miss = dev->miss;
+  p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
+  for (int k = 0; k < 2; ++k)
+  {
+    p.resolution[k]  = dev->state.resolution[k];
+    p.tileSize[k]    = dev->state.tileSize[k];
+    p.tileShift[k]   = calculateShift(dev->state.tileSize[k]);
+    p.pathLengths[k] = dev->state.pathLengths[k];
+  }
+  p.deviceCount = dev->count; p.deviceIndex = dev->index; p.distribution = dev->state.distribution;
+  p.launchWidth = dev->launchWidth;
+  p.lensShader  = dev->state.lensShader;
+  p.sceneEpsilon = dev->state.epsilonFactor * SCENE_EPSILON_SCALE;
+  p.envRotation  = dev->state.envRotation;
+  p.numPixels = dev->launchWidth * dev->state.resolution[1];
+  p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
+  p.counters = dev->d_counters;
+  p.stats = dev->statsEnabled ? dev->d_stats : nullptr;
+  p.firstHit = dev->captureFirstHits ? dev->d_firstHit : nullptr;
+  p.firstHitInstance = dev->captureFirstHits ? dev->d_firstHitInstance : nullptr;
+  p.traceStackSpill = dev->d_spill;
+}
+
+static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * 6; } // 24 KiB LDS stack per block → 6 blocks per CU
+
+static int ensureStreams(TwkDevice dev)
+{
+  const int numPixels = dev->launchWidth * dev->state.resolution[1];
+  if (numPixels > dev->allocatedPixels || dev->d_streamBlock == nullptr)
+  {
+    freeDevice(dev->d_streamBlock);
+    freeDevice(dev->d_outputInternal);
+    freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
+    const size_t n = (size_t) numPixels;
+    // float4 streams: rayOrg[2], rayDir[2], hitRecord, shadowOrg, shadowDir, shadowPending, throughput, radiance, volumeStack[4] = 14
+    // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel
+    const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned int)) + 4096;
+    HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
+    HIP_TRY(hipMalloc(&dev->d_outputInternal, n * sizeof(float4)));
+    HIP_TRY(hipMemsetAsync(dev->d_outputInternal, 0, n * sizeof(float4), dev->stream));
+    HIP_TRY(hipMalloc(&dev->d_firstHit, n * sizeof(float4)));
+    HIP_TRY(hipMalloc(&dev->d_firstHitInstance, n * sizeof(int)));
+    dev->allocatedPixels = numPixels;
+  }
+  if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
+  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 8)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 8, dev->stream)); }
+  const size_t lanes = (size_t) traceGridBlocks(dev) * TWK_TRACE_BLOCK;
+  if (lanes > dev->spillLanes)
+  {
+    freeDevice(dev->d_spill);
+    HIP_TRY(hipMalloc(&dev->d_spill, lanes * TWK_TRACE_STACK_SPILL * sizeof(int)));
+    dev->spillLanes = lanes;
+  }
+
+  // carve the block
+  LaunchParams& p = dev->params;
+  const size_t n = (size_t) dev->allocatedPixels;
+  char* base = static_cast<char*>(dev->d_streamBlock);
+  auto take = [&](size_t elemBytes) { char* r = base; base += n * elemBytes; return r; };
+  p.rayOrg[0] = (float4*) take(16); p.rayOrg[1] = (float4*) take(16);
+  p.rayDir[0] = (float4*) take(16); p.rayDir[1] = (float4*) take(16);
+  p.hitRecord = (float4*) take(16);
+  p.shadowOrg = (float4*) take(16); p.shadowDir = (float4*) take(16); p.shadowPending = (float4*) take(16);
+  p.pathThroughput = (float4*) take(16); p.pathRadiance = (float4*) take(16);
+  p.volumeStack = (float4*) take(64);
+  p.pathSeedFlags = (uint2*) take(8);
+  p.rayPixel[0] = (unsigned int*) take(4); p.rayPixel[1] = (unsigned int*) take(4);
+  p.hitInstance = (int*) take(4);
+  p.shadowPixel = (unsigned int*) take(4);
+  return TWK_SUCCESS;
+}
+
+static void timedLaunchBegin(TwkDevice dev, int kind)
+{
+  if (!dev->profileEnabled) return;
+  if (dev->timedUsed == dev->timed.size())
+  {
+    TimedLaunch t; t.kind = kind;
+    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) { dev->profileEnabled = false; return; }
+    dev->timed.push_back(t);
+  }
+  dev->timed[dev->timedUsed].kind = kind;
+  (void) hipEventRecord(dev->timed[dev->timedUsed].start, dev->stream);
+}
+
+static void timedLaunchEnd(TwkDevice dev)
+{
+  if (!dev->profileEnabled) return;
+  (void) hipEventRecord(dev->timed[dev->timedUsed].stop, dev->stream);
+  dev->timedUsed++;
+}
+
+static int collectTimed(TwkDevice dev)
+{
+  if (dev->timedUsed == 0) return TWK_SUCCESS;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  for (size_t i = 0; i < dev->timedUsed; ++i)
+  {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, dev->timed[i].start, dev->timed[i].stop));
+    dev->profileMs[dev->timed[i].kind] += ms;
+    dev->profileLaunches[dev->timed[i].kind] += 1;
+  }
+  dev->timedUsed = 0;
+  return TWK_SUCCESS;
+}
+
+// Spherical environment CDFs + integral, Texture.cpp:1499-1645.
+static float gaussianFilter(const float* rgba, unsigned int width, unsigned int height, unsigned int x, unsigned int y)
+{
+  const unsigned int left   = (0 < x)          ? x - 1 : width - 1;
+  const unsigned int right  = (x < width - 1)  ? x + 1 : 0;
+  const unsigned int bottom = (0 < y)          ? y - 1 : y;
+  const unsigned int top    = (y < height - 1) ? y + 1 : y;
+  auto sum3 = [&](unsigned int xx, unsigned int yy) { const float* q = rgba + ((size_t) width * yy + xx) * 4; return q[0] + q[1] + q[2]; };
+  float intensity = sum3(x, y) * 0.619347f;
+  float f = sum3(x, bottom);
+  f += sum3(left, y);
+  f += sum3(right, y);
+  f += sum3(x, top);
+  intensity += f * 0.0838195f;
+  f  = sum3(left, bottom);
+  f += sum3(right, bottom);
+  f += sum3(left, top);
+  f += sum3(right, top);
+  intensity += f * 0.0113437f;
+  return intensity / 3.0f;
+}
+
+static void calculateSphericalCDF(const float* rgba, unsigned int width, unsigned int height,
+                                  std::vector<float>& cdfU, std::vector<float>& cdfV, float& integralOut)
+{
+  std::vector<float> funcU((size_t) width * height), funcV(height + 1);
+  float sum = 0.0f;
+  for (unsigned int y = 0; y < height; ++y)
+  {
+    const float sinTheta = float(sin(M_PI * (double(y) + 0.5) / double(height)));
+    for (unsigned int x = 0; x < width; ++x)
+    {
+      const float value = gaussianFilter(rgba, width, height, x, y);
+      funcU[(size_t) y * width + x] = value * sinTheta;
+      const float* q = rgba + ((size_t) y * width + x) * 4;
+      const float intensity = (q[0] + q[1] + q[2]) / 3.0f;
+      sum += intensity * sinTheta;
+    }
+  }
+  integralOut = sum * 2.0f * kPi * kPi / float(width * height);
+
+  cdfU.assign((size_t) (width + 1) * height, 0.0f);
+  cdfV.assign(height + 1, 0.0f);
+  for (unsigned int y = 0; y < height; ++y)
+  {
+    const size_t row = (size_t) y * (width + 1);
+    cdfU[row] = 0.0f;
+    for (unsigned int x = 1; x <= width; ++x) cdfU[row + x] = cdfU[row + x - 1] + funcU[(size_t) y * width + x - 1];
+    const float integral = cdfU[row + width];
+    funcV[y] = integral;
+    if (integral != 0.0f) { for (unsigned int x = 1; x <= width; ++x) cdfU[row + x] /= integral; }
+    else                  { for (unsigned int x = 1; x <= width; ++x) cdfU[row + x] = float(x) / float(width); }
+  }
+  cdfV[0] = 0.0f;
+  for (unsigned int y = 1; y <= height; ++y) cdfV[y] = cdfV[y - 1] + funcV[y - 1];
+  const float integral = cdfV[height];
+  if (integral != 0.0f) { for (unsigned int y = 1; y <= height; ++y) cdfV[y] /= integral; }
+  else                  { for (unsigned int y = 1; y <= height; ++y) cdfV[y] = float(y) / float(height); }
+}
+
+// =============================================================================================
+extern "C" {
+
+const char* twk_last_error(void) { return g_lastError.c_str(); }
+int twk_abi_version(void) { return TWK_ABI_VERSION; }
+
+int twk_device_count(int* count)
+{
+  if (!count) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_device_count: NULL argument");
+  *count = 0;
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return twkSetError(TWK_ERROR_NO_DEVICE, std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e));
+  *count = n;
+  return TWK_SUCCESS;
+}
+
+int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int miss)
+{
+  if (!out) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_device_create: NULL out pointer");
+  *out = nullptr;
+  if (count < 1 || index < 0 || index >= count) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_device_create: need 0 <= index < count");
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return twkSetError(TWK_ERROR_NO_DEVICE, std::string("twk_device_create: no HIP device available (") + ((e != hipSuccess) ? hipGetErrorString(e) : "device count 0") + "); this library has no CPU path");
+  if (ordinal < 0 || ordinal >= n) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_device_create: device ordinal out of range");
+
+  TwkDevice_t* dev = new TwkDevice_t();
+  dev->ordinal = ordinal; dev->index = index; dev->count = count; dev->miss = miss;
+  memset(&dev->params, 0, sizeof(dev->params));
+  memset(&dev->state, 0, sizeof(dev->state));
+  // Device.cpp:282-303 defaults
+  dev->state.resolution[0] = dev->state.resolution[1] = 1;
+  dev->state.tileSize[0] = dev->state.tileSize[1] = 8;
+  dev->state.pathLengths[0] = 2; dev->state.pathLengths[1] = 5;
+  dev->state.epsilonFactor = 500.0f;
+  dev->state.clockFactor = 1000.0f;
+
+  hipError_t err = hipSetDevice(ordinal);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
+  hipDeviceProp_t prop;
+  if (err == hipSuccess) err = hipGetDeviceProperties(&prop, ordinal);
+  if (err != hipSuccess)
+  {
+    delete dev;
+    return twkSetError(TWK_ERROR_NO_DEVICE, std::string("twk_device_create: ") + hipGetErrorString(err));
+  }
+  dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = dev;
+  return TWK_SUCCESS;
+}
+
+int twk_device_destroy(TwkDevice dev)
+{
+  if (!dev) return TWK_SUCCESS;
+  (void) hipSetDevice(dev->ordinal);
+  if (dev->stream) (void) hipStreamSynchronize(dev->stream);
+  for (TimedLaunch& t : dev->timed) { (void) hipEventDestroy(t.start); (void) hipEventDestroy(t.stop); }
+  freeDevice(dev->d_camera); freeDevice(dev->d_lights); freeDevice(dev->d_materials);
+  freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
+  freeDevice(dev->d_nodes); freeDevice(dev->d_triangles); freeDevice(dev->d_instances);
+  for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
+  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V);
+  freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
+  freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
+  freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
+  dev->builder.release();
+  if (dev->stream) (void) hipStreamDestroy(dev->stream);
+  delete dev;
+  return TWK_SUCCESS;
+}
+
+int twk_set_state(TwkDevice dev, const TwkDeviceState* s)
+{
+  int rc = activate(dev, "twk_set_state"); if (rc) return rc;
+  if (!s) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_state: NULL state");
+  if (s->resolution[0] < 1 || s->resolution[1] < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_state: resolution must be >= 1");
+  if (s->tileSize[0] < 1 || s->tileSize[1] < 1 || (s->tileSize[0] & (s->tileSize[0] - 1)) || (s->tileSize[1] & (s->tileSize[1] - 1)))
+    return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_state: tileSize must be a power of two");
+  if (s->pathLengths[1] < 0 || s->pathLengths[1] > TWK_MAX_DEPTH) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_state: pathLengths.y must be in [0, 64]");
+  if (s->lensShader < 0 || s->lensShader > 2) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_state: lensShader must be 0..2");
+  HIP_TRY(hipStreamSynchronize(dev->stream)); // Device.cpp:1194-1195
+  dev->state = *s;
+  dev->stateSet = true;
+  if (s->distribution && 1 < dev->count)
+  {
+    // DeviceMultiGPULocalCopy.cpp:84-97
+    const int width = (s->resolution[0] + dev->count - 1) / dev->count;
+    const int mask  = s->tileSize[0] - 1;
+    dev->launchWidth = (width + mask) & ~mask;
+  }
+  else dev->launchWidth = s->resolution[0];
+  if (dev->d_outputExternal && dev->outputExternalBytes < (size_t) dev->launchWidth * s->resolution[1] * sizeof(float4))
+  {
+    dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; // too small for the new state: fall back to the internal buffer
+  }
+  return TWK_SUCCESS;
+}
+
+int twk_init_cameras(TwkDevice dev, const TwkCameraDefinition* c, int count)
+{
+  int rc = activate(dev, "twk_init_cameras"); if (rc) return rc;
+  if (!c || count < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_cameras: at least one camera is required");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->cameras.assign(c, c + count);
+  if (!dev->d_camera) HIP_TRY(hipMalloc(&dev->d_camera, sizeof(TwkCameraDefinition)));
+  HIP_TRY(hipMemcpyAsync(dev->d_camera, dev->cameras.data(), sizeof(TwkCameraDefinition), hipMemcpyHostToDevice, dev->stream)); // the lens shaders read cameraDefinitions[0]
+  return TWK_SUCCESS;
+}
+
+int twk_update_camera(TwkDevice dev, int idCamera, const TwkCameraDefinition* c)
+{
+  int rc = activate(dev, "twk_update_camera"); if (rc) return rc;
+  if (!c || idCamera < 0 || idCamera >= (int) dev->cameras.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_camera: bad camera id");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->cameras[idCamera] = *c;
+  if (idCamera == 0) HIP_TRY(hipMemcpyAsync(dev->d_camera, dev->cameras.data(), sizeof(TwkCameraDefinition), hipMemcpyHostToDevice, dev->stream));
+  return TWK_SUCCESS;
+}
+
+int twk_init_lights(TwkDevice dev, const TwkLightDefinition* l, int count)
+{
+  int rc = activate(dev, "twk_init_lights"); if (rc) return rc;
+  if (count < 0 || (count > 0 && !l)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_lights: bad arguments");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  freeDevice(dev->d_lights);
+  dev->lights.assign(l, l + count);
+  if (count > 0)
+  {
+    HIP_TRY(hipMalloc(&dev->d_lights, sizeof(DevLight) * count));
+    HIP_TRY(hipMemcpyAsync(dev->d_lights, dev->lights.data(), sizeof(DevLight) * count, hipMemcpyHostToDevice, dev->stream));
+  }
+  return TWK_SUCCESS;
+}
+
+int twk_update_light(TwkDevice dev, int idLight, const TwkLightDefinition* l)
+{
+  int rc = activate(dev, "twk_update_light"); if (rc) return rc;
+  if (!l || idLight < 0 || idLight >= (int) dev->lights.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_light: bad light id");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->lights[idLight] = *l;
+  HIP_TRY(hipMemcpyAsync(dev->d_lights + idLight, &dev->lights[idLight], sizeof(DevLight), hipMemcpyHostToDevice, dev->stream));
+  return TWK_SUCCESS;
+}
+
+int twk_init_materials(TwkDevice dev, const TwkMaterialGUI* m, int count)
+{
+  int rc = activate(dev, "twk_init_materials"); if (rc) return rc;
+  if (!m || count < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: at least one material is required");
+  for (int i = 0; i < count; ++i)
+  {
+    if (m[i].indexBSDF < 0 || m[i].indexBSDF > 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: indexBSDF out of range");
+    if (m[i].useCutoutTexture) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: cutout opacity (stochastic any-hit, anyhit.cu:46-132) is not implemented in this build");
+  }
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->materials.resize(count);
+  for (int i = 0; i < count; ++i) dev->materials[i] = convertMaterial(m[i]);
+  if (count > dev->materialCapacity)
+  {
+    freeDevice(dev->d_materials);
+    HIP_TRY(hipMalloc(&dev->d_materials, sizeof(DevMaterial) * count));
+    dev->materialCapacity = count;
+  }
+  HIP_TRY(hipMemcpyAsync(dev->d_materials, dev->materials.data(), sizeof(DevMaterial) * count, hipMemcpyHostToDevice, dev->stream));
+  return TWK_SUCCESS;
+}
+
+int twk_update_material(TwkDevice dev, int idMaterial, const TwkMaterialGUI* m)
+{
+  int rc = activate(dev, "twk_update_material"); if (rc) return rc;
+  if (!m || idMaterial < 0 || idMaterial >= (int) dev->materials.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_material: bad material id");
+  if (m->indexBSDF < 0 || m->indexBSDF > 4 || m->useCutoutTexture) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_material: unsupported material");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->materials[idMaterial] = convertMaterial(*m);
+  HIP_TRY(hipMemcpyAsync(dev->d_materials + idMaterial, &dev->materials[idMaterial], sizeof(DevMaterial), hipMemcpyHostToDevice, dev->stream));
+  return TWK_SUCCESS;
+}
+
+int twk_init_texture(TwkDevice dev, int slot, const float* rgba, int width, int height)
+{
+  int rc = activate(dev, "twk_init_texture"); if (rc) return rc;
+  if (slot < 0 || slot > 2 || !rgba || width < 1 || height < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_texture: bad arguments");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  freeDevice(dev->d_texels[slot]);
+  const size_t bytes = sizeof(float4) * (size_t) width * height;
+  HIP_TRY(hipMalloc(&dev->d_texels[slot], bytes));
+  HIP_TRY(hipMemcpy(dev->d_texels[slot], rgba, bytes, hipMemcpyHostToDevice));
+  DevTexture& t = dev->params.textures[slot];
+  t.texels = dev->d_texels[slot]; t.width = width; t.height = height; t.clampV = (slot == TWK_TEXTURE_ENVIRONMENT) ? 1 : 0; t.pad = 0;
+  if (slot == TWK_TEXTURE_ENVIRONMENT)
+  {
+    std::vector<float> cdfU, cdfV; float integral = 1.0f;
+    calculateSphericalCDF(rgba, (unsigned int) width, (unsigned int) height, cdfU, cdfV, integral);
+    freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V);
+    HIP_TRY(hipMalloc(&dev->d_envCDF_U, sizeof(float) * cdfU.size()));
+    HIP_TRY(hipMalloc(&dev->d_envCDF_V, sizeof(float) * cdfV.size()));
+    HIP_TRY(hipMemcpy(dev->d_envCDF_U, cdfU.data(), sizeof(float) * cdfU.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev->d_envCDF_V, cdfV.data(), sizeof(float) * cdfV.size(), hipMemcpyHostToDevice));
+    dev->params.envWidth = (unsigned int) width; dev->params.envHeight = (unsigned int) height; dev->params.envIntegral = integral;
+  }
+  return TWK_SUCCESS;
+}
+
+int twk_clear_scene(TwkDevice dev)
+{
+  int rc = activate(dev, "twk_clear_scene"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->geometries.clear(); dev->instances.clear(); dev->built = false;
+  return TWK_SUCCESS;
+}
+
+int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, size_t numAttributes,
+                     const unsigned int* indices, size_t numIndices, int* idGeometry)
+{
+  if (!dev) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: NULL device handle");
+  if (!attributes || !indices || numAttributes == 0 || numIndices == 0 || (numIndices % 3) != 0)
+    return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: need attributes and a non-empty multiple of three indices");
+  for (size_t i = 0; i < numIndices; ++i)
+    if (indices[i] >= numAttributes) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: index out of range");
+  GeometryHost g;
+  g.attributes.assign(attributes, attributes + numAttributes);
+  g.indices.assign(indices, indices + numIndices);
+  g.numTriangles = (int) (numIndices / 3);
+  dev->geometries.push_back(std::move(g));
+  dev->built = false;
+  if (idGeometry) *idGeometry = (int) dev->geometries.size() - 1;
+  return TWK_SUCCESS;
+}
+
+int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12], int idMaterial, int idLight, int* idInstance)
+{
+  if (!dev) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: NULL device handle");
+  if (!transform || idGeometry < 0 || idGeometry >= (int) dev->geometries.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: bad geometry id");
+  if (idMaterial < 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: an instance needs a material (Device.cpp:1429)");
+  InstanceHost inst;
+  inst.geometry = idGeometry; inst.material = idMaterial; inst.light = idLight;
+  memcpy(inst.transform, transform, sizeof(float) * 12);
+  dev->instances.push_back(inst);
+  dev->built = false;
+  if (idInstance) *idInstance = (int) dev->instances.size() - 1;
+  return TWK_SUCCESS;
+}
+
+int twk_build(TwkDevice dev)
+{
+  int rc = activate(dev, "twk_build"); if (rc) return rc;
+  if (dev->geometries.empty() || dev->instances.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: the scene has no geometry or no instance");
+  for (const InstanceHost& inst : dev->instances)
+  {
+    if (inst.material >= (int) dev->materials.size()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: instance material index beyond twk_init_materials");
+    if (inst.light >= (int) dev->lights.size()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: instance light index beyond twk_init_lights");
+  }
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+
+  // shared attribute / index arrays and the node / triangle budgets
+  size_t numAttr = 0, numIdx = 0, numTris = 0, numNodes = 0;
+  for (GeometryHost& g : dev->geometries)
+  {
+    g.attributeBase = (unsigned int) numAttr; g.indexBase = (unsigned int) numIdx;
+    g.triangleBase = (int) numTris; g.nodeBase = (int) numNodes;
+    numAttr += g.attributes.size(); numIdx += g.indices.size();
+    numTris += (size_t) g.numTriangles; numNodes += (size_t) ((g.numTriangles > 1) ? g.numTriangles - 1 : 1);
+  }
+  const int numInstances = (int) dev->instances.size();
+  const int tlasBase = (int) numNodes;
+  numNodes += (size_t) ((numInstances > 1) ? numInstances - 1 : 1);
+
+  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_triangles); freeDevice(dev->d_instances);
+  HIP_TRY(hipMalloc(&dev->d_attributes, sizeof(TwkTriangleAttributes) * numAttr));
+  HIP_TRY(hipMalloc(&dev->d_indices, sizeof(unsigned int) * numIdx));
+  HIP_TRY(hipMalloc(&dev->d_nodes, sizeof(BvhNode) * numNodes));
+  HIP_TRY(hipMalloc(&dev->d_triangles, sizeof(float4) * 3 * numTris));
+  HIP_TRY(hipMalloc(&dev->d_instances, sizeof(DevInstance) * numInstances));
+  for (const GeometryHost& g : dev->geometries)
+  {
+    HIP_TRY(hipMemcpyAsync(dev->d_attributes + 12 * (size_t) g.attributeBase, g.attributes.data(), sizeof(TwkTriangleAttributes) * g.attributes.size(), hipMemcpyHostToDevice, dev->stream));
+    HIP_TRY(hipMemcpyAsync(dev->d_indices + g.indexBase, g.indices.data(), sizeof(unsigned int) * g.indices.size(), hipMemcpyHostToDevice, dev->stream));
+  }
+
+  // bottom level: one LBVH per geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
+  for (GeometryHost& g : dev->geometries)
+  {
+    HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes + 12 * (size_t) g.attributeBase, dev->d_indices + g.indexBase, g.numTriangles,
+                                        dev->d_nodes + g.nodeBase, g.nodeBase, dev->d_triangles, g.triangleBase, g.rootBounds));
+  }
+
+  // instance records + world boxes
+  std::vector<DevInstance> records(numInstances);
+  std::vector<float4> boxLo(numInstances), boxHi(numInstances);
+  for (int i = 0; i < numInstances; ++i)
+  {
+    const InstanceHost& inst = dev->instances[i];
+    const GeometryHost& g = dev->geometries[inst.geometry];
+    DevInstance& r = records[i];
+    memset(&r, 0, sizeof(r));
+    memcpy(r.objectToWorld, inst.transform, sizeof(float) * 12);
+    invertAffine(inst.transform, r.worldToObject);
+    r.blasRoot = g.nodeBase; r.material = inst.material; r.light = inst.light;
+    r.attributeBase = g.attributeBase; r.indexBase = g.indexBase; r.geometry = inst.geometry;
+
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int corner = 0; corner < 8; ++corner)
+    {
+      const float x = g.rootBounds[(corner & 1) ? 3 : 0], y = g.rootBounds[(corner & 2) ? 4 : 1], z = g.rootBounds[(corner & 4) ? 5 : 2];
+      const float* m = inst.transform;
+      const float w[3] = { m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11] };
+      for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], w[k]); hi[k] = fmaxf(hi[k], w[k]); }
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+      // world box of an object-space box: pad for the rounding of the transform in both directions
+      const float e = 1.0e-5f * fmaxf(1.0f, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+      lo[k] -= e; hi[k] += e;
+    }
+    boxLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    boxHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+  }
+  HIP_TRY(hipMemcpyAsync(dev->d_instances, records.data(), sizeof(DevInstance) * numInstances, hipMemcpyHostToDevice, dev->stream));
+  HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), numInstances, dev->d_nodes + tlasBase, tlasBase));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+
+  dev->tlasRoot = tlasBase;
+  dev->totalNodes = numNodes; dev->totalTriangles = numTris;
+  dev->built = true;
+  return TWK_SUCCESS;
+}
+
+int twk_launch(TwkDevice dev, unsigned int iterationIndex)
+{
+  int rc = activate(dev, "twk_launch"); if (rc) return rc;
+  if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: twk_set_state has not been called (samplesSqrt 0, Device.cpp:293)");
+  if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: twk_build has not been called");
+  if (dev->cameras.empty() || dev->materials.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: cameras and materials are required");
+  if (dev->miss == 2 && dev->d_texels[TWK_TEXTURE_ENVIRONMENT] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: miss 2 needs an environment texture");
+  for (const DevMaterial& m : dev->materials)
+    if (m.textureAlbedo && dev->d_texels[TWK_TEXTURE_ALBEDO] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: a material uses the albedo texture but none was uploaded");
+
+  if ((rc = ensureStreams(dev))) return rc;
+  refreshParams(dev);
+  LaunchParams& p = dev->params;
+  p.iterationIndex = iterationIndex;
+
+  const int maxDepth = dev->state.pathLengths[1];
+  HIP_TRY(hipMemsetAsync(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (maxDepth + 2), dev->stream));
+
+  const int traceGrid = traceGridBlocks(dev);
+  int shadeGrid = (p.numPixels + 255) / 256;
+  if (shadeGrid > dev->numCUs * 8) shadeGrid = dev->numCUs * 8;
+
+  timedLaunchBegin(dev, TWK_KERNEL_GENERATE); launchGenerate(p, dev->stream); timedLaunchEnd(dev);
+  for (int depth = 0; depth < maxDepth; ++depth)
+  {
+    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, depth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
+    timedLaunchBegin(dev, TWK_KERNEL_SHADE); launchShade(p, depth, shadeGrid, dev->stream); timedLaunchEnd(dev);
+  }
+  if (maxDepth > 0)
+  {
+    // shadow rays of the last bounce
+    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, maxDepth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
+  }
+  timedLaunchBegin(dev, TWK_KERNEL_ACCUM); launchAccumulate(p, dev->stream); timedLaunchEnd(dev);
+  HIP_TRY(hipGetLastError());
+  return TWK_SUCCESS;
+}
+
+int twk_sync(TwkDevice dev)
+{
+  int rc = activate(dev, "twk_sync"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  return TWK_SUCCESS;
+}
+
+int twk_get_launch_width(TwkDevice dev, int* launchWidth)
+{
+  if (!dev || !launchWidth) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_launch_width: NULL argument");
+  *launchWidth = dev->launchWidth;
+  return TWK_SUCCESS;
+}
+
+int twk_read_output(TwkDevice dev, float* rgbaHost, size_t numFloats)
+{
+  int rc = activate(dev, "twk_read_output"); if (rc) return rc;
+  if (!rgbaHost) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: NULL buffer");
+  const size_t n = (size_t) dev->launchWidth * dev->state.resolution[1];
+  if (numFloats != n * 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: buffer must hold launchWidth*height*4 floats");
+  const float4* src = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
+  if (!src) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_read_output: nothing has been rendered");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  HIP_TRY(hipMemcpy(rgbaHost, src, n * sizeof(float4), hipMemcpyDeviceToHost));
+  return TWK_SUCCESS;
+}
+
+int twk_get_output_device_pointer(TwkDevice dev, void** dptr, size_t* bytes)
+{
+  int rc = activate(dev, "twk_get_output_device_pointer"); if (rc) return rc;
+  if (!dptr) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_output_device_pointer: NULL argument");
+  if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_get_output_device_pointer: twk_set_state first");
+  if ((rc = ensureStreams(dev))) return rc;
+  *dptr = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
+  if (bytes) *bytes = (size_t) dev->launchWidth * dev->state.resolution[1] * sizeof(float4);
+  return TWK_SUCCESS;
+}
+
+int twk_set_output_device_pointer(TwkDevice dev, void* dptr, size_t bytes)
+{
+  int rc = activate(dev, "twk_set_output_device_pointer"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (dptr == nullptr) { dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; return TWK_SUCCESS; }
+  if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_set_output_device_pointer: twk_set_state first");
+  if (bytes < (size_t) dev->launchWidth * dev->state.resolution[1] * sizeof(float4)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_output_device_pointer: buffer smaller than launchWidth*height*16 bytes");
+  dev->d_outputExternal = static_cast<float4*>(dptr); dev->outputExternalBytes = bytes;
+  return TWK_SUCCESS;
+}
+
+int twk_compositor(TwkDevice dev, const void* tiles, void* output)
+{
+  int rc = activate(dev, "twk_compositor"); if (rc) return rc;
+  if (!tiles || !output) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_compositor: NULL buffer");
+  if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_compositor: twk_set_state first");
+  launchCompositor(static_cast<const float4*>(tiles), static_cast<float4*>(output), dev->state.resolution[0], dev->state.resolution[1],
+                   dev->launchWidth, dev->count, dev->state.tileSize[0], calculateShift(dev->state.tileSize[0]), calculateShift(dev->state.tileSize[1]), dev->stream);
+  HIP_TRY(hipGetLastError());
+  return TWK_SUCCESS;
+}
+
+// ---- measurement ------------------------------------------------------------------------------
+int twk_profile_enable(TwkDevice dev, int enable)
+{
+  int rc = activate(dev, "twk_profile_enable"); if (rc) return rc;
+  if ((rc = collectTimed(dev))) return rc;
+  dev->profileEnabled = (enable != 0);
+  return TWK_SUCCESS;
+}
+
+int twk_profile_reset(TwkDevice dev)
+{
+  int rc = activate(dev, "twk_profile_reset"); if (rc) return rc;
+  if ((rc = collectTimed(dev))) return rc;
+  for (int k = 0; k < TWK_KERNEL_COUNT; ++k) { dev->profileMs[k] = 0.0f; dev->profileLaunches[k] = 0; }
+  return TWK_SUCCESS;
+}
+
+int twk_profile_get(TwkDevice dev, float ms[TWK_KERNEL_COUNT], int launches[TWK_KERNEL_COUNT])
+{
+  int rc = activate(dev, "twk_profile_get"); if (rc) return rc;
+  if ((rc = collectTimed(dev))) return rc;
+  for (int k = 0; k < TWK_KERNEL_COUNT; ++k) { if (ms) ms[k] = dev->profileMs[k]; if (launches) launches[k] = dev->profileLaunches[k]; }
+  return TWK_SUCCESS;
+}
+
+int twk_stats_enable(TwkDevice dev, int enable)
+{
+  int rc = activate(dev, "twk_stats_enable"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->statsEnabled = (enable != 0);
+  return TWK_SUCCESS;
+}
+
+int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
+{
+  int rc = activate(dev, "twk_stats_get"); if (rc) return rc;
+  if (!stats) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_stats_get: NULL argument");
+  memset(stats, 0, sizeof(*stats));
+  if (!dev->d_stats) return TWK_SUCCESS;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  unsigned long long h[8];
+  HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
+  stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6];
+  if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
+  return TWK_SUCCESS;
+}
+
+int twk_stream_peak_gbps(TwkDevice dev, size_t bytes, int repeats, float* gbps)
+{
+  int rc = activate(dev, "twk_stream_peak_gbps"); if (rc) return rc;
+  if (!gbps || bytes < 4096 || repeats < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_stream_peak_gbps: bad arguments");
+  const size_t n = bytes / sizeof(float4);
+  float4 *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc(&a, n * sizeof(float4)));
+  if (hipMalloc(&b, n * sizeof(float4)) != hipSuccess) { (void) hipFree(a); return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "twk_stream_peak_gbps: out of memory"); }
+  (void) hipMemsetAsync(a, 0, n * sizeof(float4), dev->stream);
+  hipEvent_t e0, e1;
+  (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+  launchStreamCopy(a, b, n, dev->stream); // warm-up
+  (void) hipEventRecord(e0, dev->stream);
+  for (int i = 0; i < repeats; ++i) launchStreamCopy(a, b, n, dev->stream);
+  (void) hipEventRecord(e1, dev->stream);
+  hipError_t e = hipStreamSynchronize(dev->stream);
+  float ms = 0.0f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+  (void) hipFree(a); (void) hipFree(b);
+  if (e != hipSuccess) return twkSetError(TWK_ERROR_HIP, std::string("twk_stream_peak_gbps: ") + hipGetErrorString(e));
+  *gbps = (float) (2.0 * (double) (n * sizeof(float4)) * repeats / ((double) ms * 1.0e-3) / 1.0e9);
+  return TWK_SUCCESS;
+}
+
+// ---- parity taps ------------------------------------------------------------------------------
+int twk_debug_capture(TwkDevice dev, int enable)
+{
+  int rc = activate(dev, "twk_debug_capture"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->captureFirstHits = (enable != 0);
+  return TWK_SUCCESS;
+}
+
+int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma, int* instPrim, size_t numPixels)
+{
+  int rc = activate(dev, "twk_debug_read_first_hits"); if (rc) return rc;
+  const size_t n = (size_t) dev->launchWidth * dev->state.resolution[1];
+  if (!tBetaGamma || !instPrim || numPixels != n) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_read_first_hits: size mismatch");
+  if (!dev->d_firstHit) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_read_first_hits: nothing captured");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  std::vector<float4> h(n); std::vector<int> inst(n);
+  HIP_TRY(hipMemcpy(h.data(), dev->d_firstHit, n * sizeof(float4), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(inst.data(), dev->d_firstHitInstance, n * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i)
+  {
+    tBetaGamma[3 * i] = h[i].x; tBetaGamma[3 * i + 1] = h[i].y; tBetaGamma[3 * i + 2] = h[i].z;
+    instPrim[2 * i] = inst[i];
+    int prim; memcpy(&prim, &h[i].w, 4);
+    instPrim[2 * i + 1] = (inst[i] < 0) ? -1 : prim;
+  }
+  return TWK_SUCCESS;
+}
+
+int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids)
+{
+  int rc = activate(dev, "twk_trace_rays"); if (rc) return rc;
+  if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_trace_rays: twk_build has not been called");
+  if (!rays || !tBetaGamma || !ids) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_trace_rays: NULL buffer");
+  if (numRays == 0) return TWK_SUCCESS;
+  if (!dev->stateSet) { dev->launchWidth = 1; }
+  if ((rc = ensureStreams(dev))) return rc;
+  refreshParams(dev);
+  float* d_rays = nullptr; float* d_out = nullptr; int* d_ids = nullptr;
+  HIP_TRY(hipMalloc(&d_rays, numRays * 8 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out, numRays * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_ids, numRays * 2 * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(d_rays, rays, numRays * 8 * sizeof(float), hipMemcpyHostToDevice, dev->stream));
+  int grid = (int) ((numRays + TWK_TRACE_BLOCK - 1) / TWK_TRACE_BLOCK);
+  if (grid > traceGridBlocks(dev)) grid = traceGridBlocks(dev);
+  launchTraceQuery(dev->params, d_rays, (unsigned int) numRays, anyHit, d_out, d_ids, grid, dev->stream);
+  HIP_TRY(hipMemcpyAsync(tBetaGamma, d_out, numRays * 3 * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
+  HIP_TRY(hipMemcpyAsync(ids, d_ids, numRays * 2 * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  (void) hipFree(d_rays); (void) hipFree(d_out); (void) hipFree(d_ids);
+  return TWK_SUCCESS;
+}
+
+int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n)
+{
+  int rc = activate(dev, "twk_debug_math"); if (rc) return rc;
+  if (op < 0 || op > 7 || !x || !out || (op == 3 && !y)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_math: bad arguments");
+  if (n == 0) return TWK_SUCCESS;
+  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(&dx, n * sizeof(float)));
+  HIP_TRY(hipMalloc(&dy, n * sizeof(float)));
+  HIP_TRY(hipMalloc(&dout, n * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(dx, x, n * sizeof(float), hipMemcpyHostToDevice, dev->stream));
+  HIP_TRY(hipMemcpyAsync(dy, y ? y : x, n * sizeof(float), hipMemcpyHostToDevice, dev->stream));
+  launchMathTap(op, dx, dy, dout, n, dev->stream);
+  HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  (void) hipFree(dx); (void) hipFree(dy); (void) hipFree(dout);
+  return TWK_SUCCESS;
+}
+
+} // extern "C"

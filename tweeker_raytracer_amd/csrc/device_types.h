@@ -1,0 +1,164 @@
+// Device-side data layout of the wavefront renderer (all buffers live in HBM, SoA, 16-byte records).
+//
+// Where OptiX keeps one 128-byte PerRayData per thread in local memory (shaders/per_ray_data.h:84-114)
+// and recurses raygen → trace → closesthit → trace(shadow), this renderer streams fixed-size records
+// between kernels:
+//   ray queue      32 B  (origin.xyz, tmin | direction.xyz, tmax) + 4 B launch index
+//   hit record     16 B  (t, beta, gamma, primitive) + 4 B instance
+//   path state     per launch index: throughput+pdf 16 B, radiance 16 B, seed+flags 8 B, volume stack 64 B
+//   shadow queue   ray 32 B + 4 B launch index + pending contribution 16 B
+//   BVH2 node      64 B  (two child boxes + two child references)
+//   triangle       48 B  (three float4: vertex, w of the first = primitive index)
+#pragma once
+#include "device_math.h"
+
+namespace twk {
+
+// shaders/config.h:38-46
+static const float RT_DEFAULT_MAX      = 1.e27f;
+static const float SCENE_EPSILON_SCALE = 1.0e-7f;
+static const float DENOMINATOR_EPSILON = 1.0e-6f;
+
+// shaders/per_ray_data.h:39-71
+#define TWK_MATERIAL_STACK_EMPTY (-1)
+#define TWK_MATERIAL_STACK_FIRST 0
+#define TWK_MATERIAL_STACK_LAST  3
+#define TWK_MATERIAL_STACK_SIZE  4
+#define TWK_FLAG_HIT          0x00000001u
+#define TWK_FLAG_SHADOW       0x00000002u
+#define TWK_FLAG_DIFFUSE      0x00000004u
+#define TWK_FLAG_FRONTFACE    0x00000010u
+#define TWK_FLAG_THINWALLED   0x00000020u
+#define TWK_FLAG_TRANSMISSION 0x00000100u
+#define TWK_FLAG_VOLUME       0x00001000u
+#define TWK_FLAG_TERMINATE    0x80000000u
+#define TWK_FLAG_CLEAR_MASK   TWK_FLAG_DIFFUSE
+
+// Path word packed next to the seed: bit 2 = FLAG_DIFFUSE of the last interaction (the only flag that
+// survives FLAG_CLEAR_MASK, raygeneration.cu:66), bits 8-15 depth, bits 16-18 volume stack index + 1.
+#define TWK_PATH_DEPTH_SHIFT 8
+#define TWK_PATH_STACK_SHIFT 16
+
+// ≙ MaterialDefinition (shaders/material_definition.h:37-56), 64 B
+struct DevMaterial
+{
+  float albedo[3];     float ior;
+  float absorption[3]; unsigned int flags;
+  float roughness[2];  int indexBSDF; int textureAlbedo; // texture: 0 = none, else slot + 1
+  int   textureCutout; int pad0, pad1, pad2;
+};
+
+// ≙ LightDefinition (shaders/light_definition.h:42-59), 80 B
+struct DevLight
+{
+  int   type;
+  float position[3];
+  float vecU[3];
+  float vecV[3];
+  float normal[3];
+  float area;
+  float emission[3];
+  float unused0, unused1, unused2;
+};
+
+// ≙ OptixInstance + hit-group record (src/Device.cpp:1427-1445,1492-1532), 128 B
+struct DevInstance
+{
+  float objectToWorld[12];
+  float worldToObject[12];
+  int   blasRoot;     // node index of the geometry's BVH root in the shared node array
+  int   material;
+  int   light;        // < 0: not a light
+  unsigned int attributeBase; // first TriangleAttributes of the geometry in the shared attribute array
+  unsigned int indexBase;     // first index (uint) of the geometry in the shared index array
+  int   geometry;
+  int   pad0, pad1;
+};
+
+struct DevTexture
+{
+  const float4* texels;
+  int width, height;
+  int clampV;
+  int pad;
+};
+
+// BVH2 node, 64 B. Child reference: >= 0 inner node index; < 0 leaf, payload = ~ref:
+// bottom level: triangle slot in the reordered triangle array; top level: instance index.
+struct __attribute__((aligned(16))) BvhNode
+{
+  float lo0[3]; float hi0x;
+  float hi0yz[2]; float lo1xy[2];
+  float lo1z; float hi1[3];
+  int   child0, child1, pad0, pad1;
+};
+
+#define TWK_BVH_SENTINEL 0x7fffffff
+
+// Everything a kernel needs; passed by value (≙ SystemData, shaders/system_data.h:40-90).
+struct LaunchParams
+{
+  // scene
+  const BvhNode*     nodes;
+  const float4*      triangles;      // 3 per triangle slot
+  const DevInstance* instances;
+  const float*       attributes;     // 12 floats per vertex
+  const unsigned int* indices;
+  const DevMaterial* materials;
+  const DevLight*    lights;
+  const float*       camera;         // P, U, V, W
+  DevTexture         textures[3];
+  const float*       envCDF_U;
+  const float*       envCDF_V;
+  int   tlasRoot;
+  int   numInstances;
+  int   numLights;
+  int   miss;
+  unsigned int envWidth, envHeight;
+  float envIntegral, envRotation;
+
+  // state
+  int   resolution[2];
+  int   tileSize[2];
+  int   tileShift[2];
+  int   pathLengths[2];
+  int   deviceCount, deviceIndex, distribution;
+  int   launchWidth;
+  int   lensShader;
+  unsigned int iterationIndex;
+  float sceneEpsilon;
+
+  // streams
+  float4* rayOrg[2];     // origin.xyz, tmin   — two queues, ping-pong per bounce
+  float4* rayDir[2];     // direction.xyz, tmax
+  unsigned int* rayPixel[2];
+  float4* hitRecord;     // t, beta, gamma, primitive (bits)
+  int*    hitInstance;
+  float4* shadowOrg;
+  float4* shadowDir;
+  unsigned int* shadowPixel;
+  float4* shadowPending; // throughput * NEE contribution
+  float4* pathThroughput; // xyz throughput, w pdf
+  float4* pathRadiance;
+  uint2*  pathSeedFlags;
+  float4* volumeStack;    // [4][numPixels]
+  float4* output;         // running mean, RGBA32F
+  unsigned int* counters; // see CounterSlot
+  unsigned long long* stats; // TwkLaunchStats as 7 u64, or nullptr
+  float4* firstHit;       // debug capture (t, beta, gamma, prim) or nullptr
+  int*    firstHitInstance;
+  int*    traceStackSpill; // per persistent lane overflow stack
+  int     numPixels;      // launchWidth * height
+};
+
+// Counter block layout (unsigned int each), zeroed once per launch.
+// per depth d (0..maxDepth): [d*4+0] rays in queue d, [d*4+1] shadow rays emitted by shade d,
+// [d*4+2] trace work ticket of trace launch d, [d*4+3] unused
+#define TWK_COUNTERS_PER_DEPTH 4
+#define TWK_MAX_DEPTH 64
+
+#define TWK_TRACE_STACK_LDS   24  // entries per lane in LDS
+#define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
+#define TWK_TRACE_BLOCK       256
+
+} // namespace twk

@@ -1,0 +1,196 @@
+"""Device — Python mirror of rtigo3's per-GPU `Device` interface (reference inc/Device.h:292-404).
+
+Method names follow the reference: initCameras/initLights/initMaterials/initScene-equivalents, setState,
+render(iterationIndex), synchronizeStream, getOutputBufferHost. Every method is a direct call into the
+C ABI; errors surface as TwkError (≙ the reference's std::runtime_error).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+KERNEL_CLASSES = ("generate", "trace", "shade", "accumulate")
+
+
+def device_count():
+    n = C.c_int(0)
+    L.check(L.lib.twk_device_count(C.byref(n)))
+    return n.value
+
+
+def _as_array(ctype, items):
+    items = list(items)
+    arr = (ctype * max(1, len(items)))()
+    for i, it in enumerate(items):
+        arr[i] = it
+    return arr, len(items)
+
+
+class Device:
+    def __init__(self, ordinal=0, index=0, count=1, miss=1):
+        self._h = C.c_void_p()
+        L.check(L.lib.twk_device_create(C.byref(self._h), int(ordinal), int(index), int(count), int(miss)))
+        self.index, self.count, self.miss = index, count, miss
+        self.state = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib.twk_device_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- state / scene ------------------------------------------------------------------------
+    def setState(self, state):
+        L.check(L.lib.twk_set_state(self._h, C.byref(state)))
+        self.state = state
+
+    def initCameras(self, cameras):
+        arr, n = _as_array(L.CameraDefinition, cameras)
+        L.check(L.lib.twk_init_cameras(self._h, arr, n))
+
+    def initLights(self, lights):
+        arr, n = _as_array(L.LightDefinition, lights)
+        L.check(L.lib.twk_init_lights(self._h, arr, n))
+
+    def initMaterials(self, materials):
+        arr, n = _as_array(L.MaterialGUI, materials)
+        L.check(L.lib.twk_init_materials(self._h, arr, n))
+
+    def updateCamera(self, idCamera, camera):
+        L.check(L.lib.twk_update_camera(self._h, int(idCamera), C.byref(camera)))
+
+    def updateLight(self, idLight, light):
+        L.check(L.lib.twk_update_light(self._h, int(idLight), C.byref(light)))
+
+    def updateMaterial(self, idMaterial, material):
+        L.check(L.lib.twk_update_material(self._h, int(idMaterial), C.byref(material)))
+
+    def initTexture(self, slot, rgba):
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert rgba.ndim == 3 and rgba.shape[2] == 4, "texture must be [height, width, 4] float32, row 0 = v 0"
+        L.check(L.lib.twk_init_texture(self._h, int(slot), rgba.ctypes.data_as(C.POINTER(C.c_float)),
+                                       int(rgba.shape[1]), int(rgba.shape[0])))
+
+    def clearScene(self):
+        L.check(L.lib.twk_clear_scene(self._h))
+
+    def addGeometry(self, attributes, indices):
+        """attributes: float32 [n, 12] (vertex, tangent, normal, texcoord); indices: uint32 [3 m]."""
+        attributes = np.ascontiguousarray(attributes, dtype=np.float32).reshape(-1, 12)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        gid = C.c_int(-1)
+        L.check(L.lib.twk_add_geometry(self._h, attributes.ctypes.data_as(C.c_void_p), C.c_size_t(attributes.shape[0]),
+                                       indices.ctypes.data_as(C.c_void_p), C.c_size_t(indices.shape[0]), C.byref(gid)))
+        return gid.value
+
+    def addInstance(self, idGeometry, transform, idMaterial, idLight=-1):
+        t = (C.c_float * 12)(*[float(x) for x in np.asarray(transform, dtype=np.float32).reshape(12)])
+        iid = C.c_int(-1)
+        L.check(L.lib.twk_add_instance(self._h, int(idGeometry), t, int(idMaterial), int(idLight), C.byref(iid)))
+        return iid.value
+
+    def build(self):
+        L.check(L.lib.twk_build(self._h))
+
+    # ---- rendering ----------------------------------------------------------------------------
+    def render(self, iterationIndex):
+        """≙ Device::render(iterationIndex, buffer) → optixLaunch: asynchronous, one sample per pixel."""
+        L.check(L.lib.twk_launch(self._h, C.c_uint(int(iterationIndex))))
+
+    def synchronizeStream(self):
+        L.check(L.lib.twk_sync(self._h))
+
+    @property
+    def launchWidth(self):
+        w = C.c_int(0)
+        L.check(L.lib.twk_get_launch_width(self._h, C.byref(w)))
+        return w.value
+
+    def getOutputBufferHost(self):
+        """RGBA32F running mean, shape [height, launchWidth, 4] (launchWidth == width unless tiled)."""
+        h, w = self.state.resolution[1], self.launchWidth
+        out = np.empty((h, w, 4), dtype=np.float32)
+        L.check(L.lib.twk_read_output(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(out.size)))
+        return out
+
+    def outputDevicePointer(self):
+        p, n = C.c_void_p(), C.c_size_t(0)
+        L.check(L.lib.twk_get_output_device_pointer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def setOutputDevicePointer(self, dptr, nbytes):
+        L.check(L.lib.twk_set_output_device_pointer(self._h, C.c_void_p(dptr), C.c_size_t(nbytes)))
+
+    def compositor(self, tiles_dptr, output_dptr):
+        L.check(L.lib.twk_compositor(self._h, C.c_void_p(tiles_dptr), C.c_void_p(output_dptr)))
+
+    # ---- measurement / parity taps ------------------------------------------------------------
+    def profileEnable(self, enable=True):
+        L.check(L.lib.twk_profile_enable(self._h, int(bool(enable))))
+
+    def profileReset(self):
+        L.check(L.lib.twk_profile_reset(self._h))
+
+    def profileGet(self):
+        ms = (C.c_float * 4)()
+        n = (C.c_int * 4)()
+        L.check(L.lib.twk_profile_get(self._h, ms, n))
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(KERNEL_CLASSES)}
+
+    def statsEnable(self, enable=True):
+        L.check(L.lib.twk_stats_enable(self._h, int(bool(enable))))
+
+    def statsGet(self, reset=True):
+        s = L.LaunchStats()
+        L.check(L.lib.twk_stats_get(self._h, C.byref(s), int(bool(reset))))
+        return {name: getattr(s, name) for name, _ in L.LaunchStats._fields_}
+
+    def streamPeakGBps(self, nbytes=1 << 30, repeats=10):
+        g = C.c_float(0)
+        L.check(L.lib.twk_stream_peak_gbps(self._h, C.c_size_t(nbytes), int(repeats), C.byref(g)))
+        return g.value
+
+    def debugCapture(self, enable=True):
+        L.check(L.lib.twk_debug_capture(self._h, int(bool(enable))))
+
+    def debugReadFirstHits(self):
+        n = self.state.resolution[1] * self.launchWidth
+        tbg = np.empty((n, 3), dtype=np.float32)
+        ids = np.empty((n, 2), dtype=np.int32)
+        L.check(L.lib.twk_debug_read_first_hits(self._h, tbg.ctypes.data_as(C.POINTER(C.c_float)),
+                                                ids.ctypes.data_as(C.POINTER(C.c_int)), C.c_size_t(n)))
+        return tbg, ids
+
+    def traceRays(self, rays, anyHit=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        tbg = np.zeros((n, 3), dtype=np.float32)
+        ids = np.zeros((n, 2), dtype=np.int32)
+        L.check(L.lib.twk_trace_rays(self._h, rays.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(n), int(bool(anyHit)),
+                                     tbg.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_int))))
+        return tbg, ids
+
+    def debugMath(self, op, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        yy = x if y is None else np.ascontiguousarray(y, dtype=np.float32).reshape(-1)
+        out = np.empty_like(x)
+        L.check(L.lib.twk_debug_math(self._h, int(op), x.ctypes.data_as(C.POINTER(C.c_float)),
+                                     yy.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                     C.c_size_t(x.size)))
+        return out
