@@ -268,6 +268,9 @@ int twk_camera_frustum(const float center[3], float phi, float theta, float fov,
 /* Tile map ≙ distribute() raygeneration.cu:152-164: launch column → pixel column. */
 int twk_tile_column(int launchX, int launchY, const int tileSize[2], int deviceCount, int deviceIndex, int* pixelX);
 int twk_launch_width(int width, int tileSizeX, int deviceCount, int* launchWidth); /* ≙ DeviceMultiGPULocalCopy.cpp:84-97 */
+/* Tokenise description text like Parser::getNextToken (Parser.cpp:72-148): writes "<type> <token>\n" per token
+ * (type 1 = identifier, 2 = value) into out (NUL terminated), returns the count in numTokens. */
+int twk_parse_tokens(const char* text, char* out, size_t capacity, int* numTokens);
 
 #ifdef __cplusplus
 }

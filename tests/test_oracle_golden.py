@@ -1,0 +1,116 @@
+"""CPU: the oracle against the committed golden vectors (tests/golden/oracle_cornell.npz) and against itself
+(BVH mode == brute force), plus edge cases of the optixTrace contract."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_app
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "oracle_cornell.npz"))
+
+
+def test_c1_image_and_first_hits_match_golden(twk, orc, gold):
+    app = load_app(twk, "system_rtigo3_cornell_box_c1.txt", "scene_rtigo3_cornell_box_c1.txt", (64, 64))
+    o = orc.Oracle(miss=app.info.miss)
+    o.loadApplication(app)          # BVH mode; the golden was made by brute force
+    o.captureFirstHits(True)
+    o.render(0)
+    assert np.array_equal(_bits(o.getOutputBufferHost()), _bits(gold["c1_64_spp1"]))
+    tbg, ids = o.readFirstHits()
+    assert np.array_equal(ids, gold["c1_64_firsthit_ids"])
+    hit = ids[:, 0] >= 0
+    assert np.array_equal(_bits(tbg[hit]), _bits(gold["c1_64_firsthit_tbg"][hit]))
+    o.render(1)
+    assert np.array_equal(_bits(o.getOutputBufferHost()), _bits(gold["c1_64_spp2"]))
+
+
+def test_c2_image_matches_golden(twk, orc, gold):
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (64, 36))
+    o = orc.Oracle(miss=app.info.miss)
+    o.loadApplication(app)
+    for it in range(2):
+        o.render(it)
+    img = o.getOutputBufferHost()
+    assert np.array_equal(_bits(img), _bits(gold["c2_64x36_spp2"]))
+    assert (img[..., 3] == 1.0).all() and np.isfinite(img).all()
+
+
+def test_running_mean_is_the_reference_lerp(twk, orc, gold):
+    """raygeneration.cu:246-253: dst + (x - dst) / (i + 1) in float, not sum / n."""
+    app = load_app(twk, "system_rtigo3_cornell_box_c1.txt", "scene_rtigo3_cornell_box_c1.txt", (64, 64))
+    o = orc.Oracle(miss=app.info.miss)
+    o.loadApplication(app)
+    o.render(1)  # iteration 1 alone lerps against a zero buffer: out = 0 + 0.5 * (x - 0)
+    half = o.getOutputBufferHost()[..., :3]
+    a = gold["c1_64_spp1"][..., :3]
+    both = gold["c1_64_spp2"][..., :3]
+    x1 = half / np.float32(0.5)
+    expect = a + np.float32(0.5) * (x1 - a)
+    assert np.array_equal(_bits(expect), _bits(both))
+
+
+def test_trace_contract_edge_cases(twk, orc):
+    o = orc.Oracle(miss=0)
+    attr, idx = twk.mesh_plane(1, 1, 1)  # y = 0, x,z in [-1,1], normal +y
+    g = o.addGeometry(attr, idx)
+    ident = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]
+    o.addInstance(g, ident, 0)
+    o.addInstance(g, [2, 0, 0, 0, 0, 1, 0, -1, 0, 0, 2, 0], 0)  # scaled copy at y = -1
+    rays = np.array([
+        [0.25, 1, 0.25, 0, 0, -1, 0, 1e27],     # hits instance 0 at t = 1
+        [0.25, 1, 0.25, 0, 0, -1, 0, 1.0],      # tmax exclusive: falls through to ... nothing closer than 1 → miss
+        [0.25, 1, 0.25, 1.0, 0, -1, 0, 1e27],   # tmin exclusive: skips t = 1, hits the copy at t = 2
+        [1.5, 1, 0.0, 0, 0, -1, 0, 1e27],       # outside the small plane, inside the scaled one
+        [0.25, -2, 0.25, 0, 0, 1, 0, 1e27],     # from below: back faces are hit (no culling), closest is the copy
+        [5, 1, 5, 0, 0, -1, 0, 1e27],           # miss
+        [0.0, 1, 0.0, 0, 0, -1, 0, 1e27],       # exactly on the shared diagonal edge: watertight, lower primitive wins
+        [0.25, 1, 0.25, 0, 1, 0, 0, 1e27],      # parallel to the plane
+    ], np.float32)
+    for mode in (True, False):
+        o.setTraceMode(mode)
+        tbg, ids = o.traceRays(rays)
+        assert ids[0].tolist() == [0, 1] or ids[0].tolist() == [0, 0]
+        assert tbg[0, 0] == 1.0
+        assert ids[1, 0] == -1
+        assert ids[2, 0] == 1 and tbg[2, 0] == 2.0
+        assert ids[3, 0] == 1
+        assert ids[4, 0] == 1 and tbg[4, 0] == 1.0
+        assert ids[5, 0] == -1
+        assert ids[6].tolist() == [0, 0] and tbg[6, 0] == 1.0
+        assert ids[7, 0] == -1
+        occ = o.traceRays(rays, anyHit=True)[1][:, 0]
+        assert occ.tolist() == [1, 0, 1, 1, 1, 0, 1, 0]
+    # barycentrics: beta weights vertex 1, gamma vertex 2 (closesthit.cu:142-147)
+    tbg, ids = o.traceRays(rays[:1])
+    tri = idx.reshape(-1, 3)[ids[0, 1]]
+    b, c = tbg[0, 1], tbg[0, 2]
+    p = attr[tri[0], :3] * (1 - b - c) + attr[tri[1], :3] * b + attr[tri[2], :3] * c
+    assert np.allclose(p, [0.25, 0, 0.25], atol=1e-6)
+
+
+def test_bvh_mode_equals_brute_force_on_random_rays(twk, orc):
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (16, 16))
+    o = orc.Oracle(miss=app.info.miss)
+    o.loadApplication(app)
+    rng = np.random.default_rng(11)
+    n = 600
+    org = rng.uniform(-0.9, 0.9, (n, 3)).astype(np.float32)
+    org[:, 1] += 1.0
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 5e-5, np.float32), d, np.full((n, 1), 1e27, np.float32)], 1).astype(np.float32)
+    o.setTraceMode(True)
+    a = o.traceRays(rays)
+    o.setTraceMode(False)
+    b = o.traceRays(rays)
+    assert np.array_equal(a[1], b[1])
+    hit = a[1][:, 0] >= 0
+    assert np.array_equal(_bits(a[0][hit]), _bits(b[0][hit]))

@@ -9,9 +9,9 @@ from ._lib import (TwkError, CameraDefinition, LightDefinition, MaterialGUI, Tri
                    LaunchStats, AppInfo, LIB_PATH)
 from .device import Device, device_count
 from .application import Application, mesh_plane, mesh_box, mesh_sphere, mesh_torus, mesh_parallelogram, \
-    camera_frustum, tile_column, launch_width
+    camera_frustum, tile_column, launch_width, parse_tokens
 
 __all__ = ["Device", "Application", "TwkError", "device_count", "CameraDefinition", "LightDefinition",
            "MaterialGUI", "TriangleAttributes", "DeviceState", "LaunchStats", "AppInfo", "LIB_PATH",
            "mesh_plane", "mesh_box", "mesh_sphere", "mesh_torus", "mesh_parallelogram", "camera_frustum",
-           "tile_column", "launch_width"]
+           "tile_column", "launch_width", "parse_tokens"]

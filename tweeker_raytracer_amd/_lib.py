@@ -80,7 +80,7 @@ SYMBOLS = [
     "twk_app_get_state", "twk_app_get_cameras", "twk_app_get_lights", "twk_app_get_materials",
     "twk_app_get_geometry_sizes", "twk_app_get_geometry", "twk_app_get_instance", "twk_app_init_device",
     "twk_mesh_plane", "twk_mesh_box", "twk_mesh_sphere", "twk_mesh_torus", "twk_mesh_parallelogram",
-    "twk_camera_frustum", "twk_tile_column", "twk_launch_width",
+    "twk_camera_frustum", "twk_tile_column", "twk_launch_width", "twk_parse_tokens",
 ]
 
 if not os.path.exists(LIB_PATH):

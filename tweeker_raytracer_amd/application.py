@@ -141,3 +141,17 @@ def launch_width(width, tileSizeX, deviceCount):
     w = C.c_int(0)
     L.check(L.lib.twk_launch_width(int(width), int(tileSizeX), int(deviceCount), C.byref(w)))
     return w.value
+
+
+def parse_tokens(text):
+    """Token stream of a description text: list of (type, token), type 1 = identifier, 2 = value (Parser.cpp:72-148)."""
+    buf = C.create_string_buffer(max(4096, 4 * len(text) + 64))
+    n = C.c_int(0)
+    L.check(L.lib.twk_parse_tokens(text.encode(), buf, C.c_size_t(len(buf)), C.byref(n)))
+    out = []
+    for line in buf.value.decode().split("\n"):
+        if line:
+            t, _, tok = line.partition(" ")
+            out.append((int(t), tok))
+    assert len(out) == n.value
+    return out

@@ -1,6 +1,7 @@
 // C entry points of the host scene layer declared in include/tweeker_hip.h (twk_app_*, twk_mesh_*,
 // twk_camera_frustum, twk_tile_column, twk_launch_width). Pure host code: usable without a GPU.
 #include "application.h"
+#include "description_parser.h"
 #include "../error_state.h"
 
 #include <cstring>
@@ -223,6 +224,26 @@ int twk_launch_width(int width, int tileSizeX, int deviceCount, int* launchWidth
   const int w    = (width + deviceCount - 1) / deviceCount;
   const int mask = tileSizeX - 1;
   *launchWidth = (w + mask) & ~mask;
+  return TWK_SUCCESS;
+}
+
+int twk_parse_tokens(const char* text, char* out, size_t capacity, int* numTokens)
+{
+  if (!text || !out || !numTokens) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_parse_tokens: NULL argument");
+  DescriptionParser parser;
+  parser.loadString(text);
+  std::string result, token;
+  int count = 0;
+  TokenType t;
+  while ((t = parser.nextToken(token)) != TOKEN_EOF)
+  {
+    result += std::to_string((int) t) + " " + token + "\n";
+    ++count;
+    if (t == TOKEN_UNKNOWN) break;
+  }
+  if (result.size() + 1 > capacity) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_parse_tokens: output buffer too small");
+  memcpy(out, result.c_str(), result.size() + 1);
+  *numTokens = count;
   return TWK_SUCCESS;
 }
 

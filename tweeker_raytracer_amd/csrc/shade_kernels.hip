@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(256) shadeKernel(LaunchParams p, int depth)
   const int q = depth & 1, qn = q ^ 1;
   unsigned int* nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + 0];
   unsigned int* shadowCount = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 1];
+  unsigned int statHit = 0, statMiss = 0;
 
   for (unsigned int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numRays; slot += gridDim.x * blockDim.x)
   {
@@ -754,7 +755,22 @@ __global__ void __launch_bounds__(256) shadeKernel(LaunchParams p, int depth)
 
     if (p.stats != nullptr)
     {
-      atomicAdd(&p.stats[(instanceIndex < 0) ? 6 : 5], 1ull);
+      if (instanceIndex < 0) ++statMiss; else ++statHit;
+    }
+  }
+
+  if (p.stats != nullptr)
+  {
+    // one atomic per wave, not per path
+    for (int offset = 32; offset > 0; offset >>= 1)
+    {
+      statHit  += __shfl_down(statHit, offset);
+      statMiss += __shfl_down(statMiss, offset);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+      if (statHit)  atomicAdd(&p.stats[5], (unsigned long long) statHit);
+      if (statMiss) atomicAdd(&p.stats[6], (unsigned long long) statMiss);
     }
   }
 }
