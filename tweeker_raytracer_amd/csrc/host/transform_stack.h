@@ -2,7 +2,7 @@
 // rtigo3 keeps a row-vector 4x4 matrix (nvpro-pipeline dp::math), post-multiplies every new transform
 // (curMatrix *= M, reference Application.cpp:1612-1690) and emits the transposed upper 3x4 block per
 // instance (Application.cpp:1353-1359). The float arithmetic below follows dp::math so the instance
-// matrices are identical: axis normalised in double (dp/math/Vecnt.h:832-839), degrees→radians with a
+// matrices are identical: axis normalised in float (dp/math/Vecnt.h:822-830), degrees→radians with a
 // float PI/180 (dp/math/math.h:52,91-94), quaternion from axis/angle (dp/math/Quatt.h:326-333),
 // quaternion→3x3 (dp/math/Matmnt.h:1099-1111), 4x4 product as an in-order accumulation from zero
 // (dp/math/Matmnt.h:1005-1020).
@@ -64,19 +64,21 @@ public:
 
   void rotate(float ax, float ay, float az, float degrees)
   {
-    // axis.normalize() in double
-    double dx = ax, dy = ay, dz = az;
-    double sq = 0.0; sq += dx * dx; sq += dy * dy; sq += dz * dz;
-    const double norm = std::sqrt(sq);
-    if (std::numeric_limits<double>::epsilon() < norm) { dx /= norm; dy /= norm; dz /= norm; }
-    const float x0 = (float) dx, y0 = (float) dy, z0 = (float) dz;
+    // axis.normalize(): single precision, in-order sum of squares, divide when the length exceeds epsilon
+    // (dp/math/Vecnt.h:822-830; the reference-built helper in oracle/_ref pins that the float path is taken)
+    float x0 = ax, y0 = ay, z0 = az;
+    float sq = 0.0f; sq += x0 * x0; sq += y0 * y0; sq += z0 * z0;
+    const float norm = sqrtf(sq);
+    if (std::numeric_limits<float>::epsilon() < norm) { x0 /= norm; y0 /= norm; z0 /= norm; }
 
-    const float PI = 4 * atanf(1.0f);
+    const float PI = (float) (4 * atan(1.0));
     const float angle = degrees * (PI / 180);
 
-    const float s = sinf(0.5f * angle);
+    // Quatt(axis, angle): sin / cos of the half angle are evaluated in double and rounded (dp/math/Quatt.h:326-333
+    // calls the C functions with a float argument)
+    const float s = (float) sin((double) (0.5f * angle));
     const float x = x0 * s, y = y0 * s, z = z0 * s;
-    const float w = cosf(0.5f * angle);
+    const float w = (float) cos((double) (0.5f * angle));
 
     Matrix44 r = Matrix44::identity();
     r.m[0][0] = 1 - 2 * (y * y + z * z); r.m[0][1] = 2 * (x * y + z * w);     r.m[0][2] = 2 * (x * z - y * w);
