@@ -131,6 +131,7 @@ typedef struct TwkLaunchStats
   uint64_t instancesEntered;
   uint64_t shadedHits;
   uint64_t missed;
+  uint64_t maxNodesPerRay;  /* longest single traversal (inner-node visits) seen */
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */

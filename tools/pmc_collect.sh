@@ -1,0 +1,19 @@
+#!/bin/bash
+# PMC collection on the GPU box: separate rocprofv3 passes (SQ has 8 slots, TCC 4; FETCH_SIZE takes 3, WRITE_SIZE 2),
+# counters only combined with --kernel-trace. Output: gpurun_out/pmc/<pass>/..._counter_collection.csv
+# usage: tools/pmc_collect.sh <tag> [bench args]
+set -u
+TAG=${1:-pmc}; shift || true
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-roofline $*"
+run() { # name counters...
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
+run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD SQ_WAVES SQ_INSTS_VALU_TRANS_F32
+run tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
+run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+find $OUT -name "*.csv" | head -20

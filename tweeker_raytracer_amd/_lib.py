@@ -55,7 +55,7 @@ class DeviceState(C.Structure):
 class LaunchStats(C.Structure):
     _fields_ = [("radianceRays", C.c_uint64), ("shadowRays", C.c_uint64), ("nodesVisited", C.c_uint64),
                 ("trianglesTested", C.c_uint64), ("instancesEntered", C.c_uint64), ("shadedHits", C.c_uint64),
-                ("missed", C.c_uint64)]
+                ("missed", C.c_uint64), ("maxNodesPerRay", C.c_uint64)]
 
 
 class AppInfo(C.Structure):

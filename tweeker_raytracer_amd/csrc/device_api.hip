@@ -820,7 +820,7 @@ int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
   unsigned long long h[8];
   HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
-  stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6];
+  stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }

@@ -160,5 +160,6 @@ struct LaunchParams
 #define TWK_TRACE_STACK_LDS   24  // entries per lane in LDS
 #define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
 #define TWK_TRACE_BLOCK       256
+#define TWK_TRACE_TICKET      64   // queue slots per wave ticket (coarser tickets starve the chip: a launch holds only ~18 groups per wave)
 
 } // namespace twk

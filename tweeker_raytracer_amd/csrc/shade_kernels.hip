@@ -503,6 +503,19 @@ TWK_D void sampleLight(const LaunchParams& p, int index, const V3& point, float 
   }
 }
 
+// Queue append: one atomic per wave for all lanes that call it together (ballot + prefix popcount).
+TWK_D unsigned int waveAppend(unsigned int* counter)
+{
+  const unsigned long long mask = __ballot(1);
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long) mask) - 1;
+  unsigned int base = 0;
+  if ((int) lane == leader) base = atomicAdd(counter, (unsigned int) __popcll(mask));
+  base = __shfl(base, leader);
+  return base + rank;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One thread per ray of queue (depth & 1): miss or closest-hit shading, next-event estimation,
 // then the integrator's loop tail. Appends the continuation ray to queue ((depth + 1) & 1) and the
@@ -707,7 +720,7 @@ __global__ void __launch_bounds__(256) shadeKernel(LaunchParams p, int depth)
     }
     else
     {
-      const unsigned int s = atomicAdd(shadowCount, 1u);
+      const unsigned int s = waveAppend(shadowCount);
       const V3 pending = throughput * contribution;
       p.shadowOrg[s]     = make_float4(prd.pos.x, prd.pos.y, prd.pos.z, p.sceneEpsilon);
       p.shadowDir[s]     = make_float4(shadowDir.x, shadowDir.y, shadowDir.z, shadowTmax);
@@ -747,7 +760,7 @@ __global__ void __launch_bounds__(256) shadeKernel(LaunchParams p, int depth)
     {
       p.pathThroughput[pixel] = make_float4(throughput.x, throughput.y, throughput.z, prd.pdf);
       p.pathSeedFlags[pixel]  = make_uint2(prd.seed, (prd.flags & TWK_FLAG_CLEAR_MASK) | ((unsigned int) (stackIdx + 1) << TWK_PATH_STACK_SHIFT));
-      const unsigned int n = atomicAdd(nextCount, 1u);
+      const unsigned int n = waveAppend(nextCount);
       p.rayOrg[qn][n]   = make_float4(prd.pos.x, prd.pos.y, prd.pos.z, p.sceneEpsilon);
       p.rayDir[qn][n]   = make_float4(prd.wi.x, prd.wi.y, prd.wi.z, RT_DEFAULT_MAX);
       p.rayPixel[qn][n] = pixel;

@@ -18,7 +18,7 @@ namespace twk {
 
 struct TraceRay
 {
-  V3 o, d, id; // origin, direction, guarded reciprocal direction
+  V3 o, d, id, ood; // origin, direction, guarded reciprocal direction, origin * reciprocal direction
 };
 
 TWK_D float guardedReciprocal(float d)
@@ -31,19 +31,22 @@ TWK_D float guardedReciprocal(float d)
 TWK_D void setupRay(TraceRay& r, const V3& o, const V3& d)
 {
   r.o = o; r.d = d;
-  r.id = v3(guardedReciprocal(d.x), guardedReciprocal(d.y), guardedReciprocal(d.z));
+  r.id  = v3(guardedReciprocal(d.x), guardedReciprocal(d.y), guardedReciprocal(d.z));
+  r.ood = v3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
 }
 
-// Conservative slab test of one child box. Returns entry distance, or a value > tfar limit on miss.
+// Conservative slab test of one child box: plane distances as one fused multiply-add each (the box test only
+// culls, its rounding is not part of the result; the 2.5e-6 relative widening covers fma-vs-exact differences,
+// and boxes are padded at build time). Returns the entry distance for near/far ordering.
 TWK_D bool slabTest(const TraceRay& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float tmax, float& tnear)
 {
-  const float x0 = (lox - r.o.x) * r.id.x, x1 = (hix - r.o.x) * r.id.x;
-  const float y0 = (loy - r.o.y) * r.id.y, y1 = (hiy - r.o.y) * r.id.y;
-  const float z0 = (loz - r.o.z) * r.id.z, z1 = (hiz - r.o.z) * r.id.z;
+  const float x0 = __builtin_fmaf(lox, r.id.x, -r.ood.x), x1 = __builtin_fmaf(hix, r.id.x, -r.ood.x);
+  const float y0 = __builtin_fmaf(loy, r.id.y, -r.ood.y), y1 = __builtin_fmaf(hiy, r.id.y, -r.ood.y);
+  const float z0 = __builtin_fmaf(loz, r.id.z, -r.ood.z), z1 = __builtin_fmaf(hiz, r.id.z, -r.ood.z);
   const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
   const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
   tnear = tn;
-  return tn * 0.9999995f <= tf * 1.0000005f;
+  return tn * 0.9999975f <= tf * 1.0000025f;
 }
 
 struct WoopConstants
@@ -228,13 +231,25 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
 
 // Persistent traversal launch for bounce `depth`: slots [0, numClosest) are the radiance rays of queue
 // (depth & 1), slots [numClosest, numClosest + numShadow) the shadow rays emitted by shade(depth - 1).
+//
+// Structure (persistent threads with per-lane refill, after Aila & Laine 2009, re-tiled for 64-wide waves):
+//   * a wave owns a small pool of consecutive queue slots, refilled 64 at a time with ONE atomic ticket;
+//   * every lane carries one ray; when fewer than TWK_TRACE_REFILL lanes still hold a ray the wave leaves the
+//     traversal loop and hands fresh slots from its pool to the idle lanes (ballot + prefix popcount, no atomics) —
+//     ray lengths on this workload range from 3 to 100+ node visits, and without refill the wave idles on its
+//     slowest lane (measured: 10.5 of 64 lanes active per VALU instruction);
+//   * "while-while": all lanes first descend inner nodes together, then handle their leaf / instance entry /
+//     instance exit once, so a wave does not pay for three code paths per step.
+#define TWK_TRACE_REFILL 44
+
 template<bool COUNT>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK)
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, 6) // 6 waves/SIMD = the 6 blocks per CU the 24-KiB LDS stacks admit
 traceKernel(LaunchParams p, int depth)
 {
   __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
   int* ldsStack = stackStorage + threadIdx.x;
   int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
+  const int stride = TWK_TRACE_BLOCK;
 
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const unsigned int numShadow  = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + 1] : 0u;
@@ -243,55 +258,209 @@ traceKernel(LaunchParams p, int depth)
 
   const int q = depth & 1;
   const unsigned int lane = threadIdx.x & 63u;
+  const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
-  unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0;
+  unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0, maxSteps = 0;
+
+  // Wave-uniform pool of queue slots. The FIRST ticket of every wave is static (wave w owns slots
+  // [w * T, (w + 1) * T)), later ones come from the atomic counter and start behind the static region: an empty
+  // or nearly empty launch (deep bounces) touches no atomic at all — 6144 waves hitting one counter word cost
+  // ~100 us per launch before (measured with an all-miss camera). T adapts to the queue: short queues are spread
+  // over all waves (down to 16 rays per wave) instead of filling a quarter of the chip with 64-ray batches.
+  const unsigned int numWaves = gridDim.x * (TWK_TRACE_BLOCK / 64);
+  const unsigned int waveId   = blockIdx.x * (TWK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+  unsigned int ticketSize = (total + numWaves - 1u) / numWaves;
+  ticketSize = min(64u, max(16u, (ticketSize + 15u) & ~15u));
+  const unsigned int staticEnd = numWaves * ticketSize; // slots handed out without the counter
+  unsigned int poolBase = waveId * ticketSize;
+  unsigned int poolCount = (poolBase < total) ? min(ticketSize, total - poolBase) : 0u;
+  bool exhausted = (poolCount == 0u);
+  if (exhausted) return;
+
+  // per-lane ray state
+  bool hasRay = false, anyHit = false, done = false; // done: the lane's ray completed and its result is not yet written
+  unsigned int slot = 0;
+  V3 org = v3(0.0f), dir = v3(0.0f);
+  float tmin = 0.0f;
+  TraceResult res; res.t = 0.0f; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1;
+  TraceRay ray; ray.o = v3(0.0f); ray.d = v3(0.0f); ray.id = v3(0.0f);
+  WoopConstants woop; woop.kx = 0; woop.ky = 1; woop.kz = 2; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
+  int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
+  unsigned int guard = 0;
+
+#define TWK_PUSH(v) do { if (sp < TWK_TRACE_STACK_LDS) ldsStack[sp * stride] = (v); else if (sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) spill[sp - TWK_TRACE_STACK_LDS] = (v); ++sp; } while (0)
+#define TWK_POP(v)  do { --sp; (v) = (sp < TWK_TRACE_STACK_LDS) ? ldsStack[sp * stride] : ((sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) ? spill[sp - TWK_TRACE_STACK_LDS] : TWK_BVH_SENTINEL); } while (0)
 
   for (;;)
   {
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(ticket, 64u);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= total) break;
-
-    const unsigned int slot = base + lane;
-    if (slot < total)
+    // ---- refill idle lanes from the wave's pool ------------------------------------------------------
     {
-      if (slot < numClosest)
+      const unsigned long long idle = __ballot(!hasRay);
+      if (idle != 0ull && !exhausted)
       {
-        const float4 o = p.rayOrg[q][slot];
-        const float4 d = p.rayDir[q][slot];
-        TraceResult res;
-        traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, false, ldsStack, spill, res, nodeCount, triCount, instCount);
-        p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
-        p.hitInstance[slot] = res.instance;
-        if (COUNT) ++closestCount;
-        if (p.firstHit != nullptr && depth == 0)
+        if (poolCount == 0u)
         {
-          const unsigned int pixel = p.rayPixel[q][slot];
-          p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
-          p.firstHitInstance[pixel] = res.instance;
+          if (staticEnd >= total) exhausted = true; // everything was handed out statically
+          else
+          {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(ticket, (unsigned int) TWK_TRACE_TICKET);
+            base = __builtin_amdgcn_readfirstlane(base) + staticEnd;
+            if (base >= total) exhausted = true;
+            else { poolBase = base; poolCount = min((unsigned int) TWK_TRACE_TICKET, total - base); }
+          }
+        }
+        if (poolCount != 0u)
+        {
+          const unsigned int rank = (unsigned int) __popcll(idle & laneBelow);
+          const unsigned int take = min(poolCount, (unsigned int) __popcll(idle));
+          if (!hasRay && rank < take)
+          {
+            slot = poolBase + rank;
+            float4 o, d;
+            if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; anyHit = false; }
+            else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; anyHit = true; }
+            org = v3(o); dir = v3(d); tmin = o.w;
+            res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1;
+            setupRay(ray, org, dir);
+            currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
+            hasRay = true;
+          }
+          poolBase += take; poolCount -= take;
         }
       }
-      else
+      if (__ballot(hasRay) == 0ull)
       {
-        const unsigned int s = slot - numClosest;
-        const float4 o = p.shadowOrg[s];
-        const float4 d = p.shadowDir[s];
-        TraceResult res;
-        traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, true, ldsStack, spill, res, nodeCount, triCount, instCount);
-        if (COUNT) ++shadowCount;
-        if (res.instance < 0)
-        {
-          // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)
-          const unsigned int pixel = p.shadowPixel[s];
-          const float4 c = p.shadowPending[s];
-          float4 r = p.pathRadiance[pixel];
-          r.x += c.x; r.y += c.y; r.z += c.z;
-          p.pathRadiance[pixel] = r;
-        }
+        if (exhausted) break;
+        continue; // pool was empty and the new ticket arrives next round
       }
     }
+
+    // ---- traverse until enough lanes have finished to be worth a refill ------------------------------
+    for (;;)
+    {
+      // all lanes descend inner nodes
+      while (hasRay && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
+      {
+        const float4* n = reinterpret_cast<const float4*>(p.nodes + node);
+        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        if (COUNT) ++nodeCount;
+        float t0, t1;
+        const bool h0 = slabTest(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, res.t, t0);
+        const bool h1 = slabTest(ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, res.t, t1);
+        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+        if (h0 && h1)
+        {
+          const bool firstIs0 = (t0 <= t1);
+          TWK_PUSH(firstIs0 ? c1 : c0);
+          node = firstIs0 ? c0 : c1;
+        }
+        else if (h0) node = c0;
+        else if (h1) node = c1;
+        else if (sp == 0) { hasRay = false; done = true; } // traversal complete, result written below
+        else TWK_POP(node);
+        if (++guard > (1u << 22)) { hasRay = false; done = true; }
+      }
+
+      // one leaf / instance-entry / instance-exit step per lane
+      if (hasRay)
+      {
+        bool pop = false;
+        if (node == TWK_BVH_SENTINEL)
+        {
+          setupRay(ray, org, dir); // back to the world-space ray
+          currentInstance = -1;
+          pop = true;
+        }
+        else
+        {
+          const int payload = ~node;
+          if (currentInstance < 0)
+          {
+            const DevInstance* inst = p.instances + payload;
+            if (COUNT) ++instCount;
+            float m[12];
+            const float4* mw = reinterpret_cast<const float4*>(inst->worldToObject);
+            const float4 r0 = mw[0], r1 = mw[1], r2 = mw[2];
+            m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w;
+            m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
+            m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w;
+            const V3 objOrg = transformPoint(m, org);
+            const V3 objDir = transformVector(m, dir);
+            setupRay(ray, objOrg, objDir);
+            woopSetup(objDir, woop);
+            currentInstance = payload;
+            TWK_PUSH(TWK_BVH_SENTINEL);
+            node = inst->blasRoot;
+          }
+          else
+          {
+            const float4* tri = p.triangles + 3 * (size_t) payload;
+            const float4 a = tri[0], b = tri[1], c = tri[2];
+            if (COUNT) ++triCount;
+            float t, beta, gamma;
+            pop = true;
+            if (woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+            {
+              const int prim = __float_as_int(a.w);
+              const bool closer = (t < res.t) ||
+                                  (t == res.t && res.instance >= 0 &&
+                                   (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
+              if (closer)
+              {
+                res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
+                if (anyHit) { pop = false; hasRay = false; done = true; }
+              }
+            }
+          }
+        }
+        if (pop)
+        {
+          if (sp == 0) { hasRay = false; done = true; }
+          else TWK_POP(node);
+        }
+      }
+
+      // write the result of rays that completed in this round
+      if (done)
+      {
+        done = false;
+        if (COUNT) maxSteps = max(maxSteps, guard);
+        if (!anyHit)
+        {
+          p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+          p.hitInstance[slot] = res.instance;
+          if (COUNT) ++closestCount;
+          if (p.firstHit != nullptr && depth == 0)
+          {
+            const unsigned int pixel = p.rayPixel[q][slot];
+            p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+            p.firstHitInstance[pixel] = res.instance;
+          }
+        }
+        else
+        {
+          if (COUNT) ++shadowCount;
+          if (res.instance < 0)
+          {
+            // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)
+            const unsigned int s = slot - numClosest;
+            const unsigned int pixel = p.shadowPixel[s];
+            const float4 c = p.shadowPending[s];
+            float4 r = p.pathRadiance[pixel];
+            r.x += c.x; r.y += c.y; r.z += c.z;
+            p.pathRadiance[pixel] = r;
+          }
+        }
+      }
+
+      const unsigned long long active = __ballot(hasRay);
+      if (active == 0ull) break;
+      if (!exhausted && __popcll(active) < min(TWK_TRACE_REFILL, (int) ticketSize)) break;
+    }
   }
+#undef TWK_PUSH
+#undef TWK_POP
 
   if (COUNT)
   {
@@ -300,6 +469,7 @@ traceKernel(LaunchParams p, int depth)
     atomicAdd(&p.stats[2], (unsigned long long) nodeCount);
     atomicAdd(&p.stats[3], (unsigned long long) triCount);
     atomicAdd(&p.stats[4], (unsigned long long) instCount);
+    atomicMax(&p.stats[7], (unsigned long long) maxSteps);
   }
 }
 
