@@ -19,6 +19,7 @@ public:
   hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, int nodeBase);
 
   void release();
+  void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 8) ? 8 : n); }
 
 private:
   hipError_t reserve(int count);
@@ -28,6 +29,8 @@ private:
   float4* m_primLo = nullptr; float4* m_primHi = nullptr;
   unsigned long long* m_keysIn = nullptr; unsigned long long* m_keysOut = nullptr;
   int* m_left = nullptr; int* m_right = nullptr; int* m_innerParent = nullptr; int* m_leafParent = nullptr;
+  int2* m_range = nullptr;
+  int m_maxLeaf = 4; // triangles per bottom-level leaf (1..8)
   unsigned int* m_tickets = nullptr;
   float4* m_nodeLo = nullptr; float4* m_nodeHi = nullptr;
   unsigned int* m_bounds = nullptr;

@@ -106,7 +106,8 @@ TWK_D int commonPrefix(const unsigned long long* __restrict__ keys, int count, i
 // One thread per inner node. childRef encoding while building: >= 0 inner node, < 0 leaf ~position.
 __global__ void radixTreeKernel(const unsigned long long* __restrict__ keys, int count,
                                 int* __restrict__ left, int* __restrict__ right,
-                                int* __restrict__ innerParent, int* __restrict__ leafParent)
+                                int* __restrict__ innerParent, int* __restrict__ leafParent,
+                                int2* __restrict__ range)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count - 1) return;
@@ -136,6 +137,7 @@ __global__ void radixTreeKernel(const unsigned long long* __restrict__ keys, int
   const int rightRef = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
   left[i]  = leftRef;
   right[i] = rightRef;
+  range[i] = make_int2(lo, hi - lo + 1); // sorted positions covered by this node: first, count
   if (leftRef  >= 0) innerParent[leftRef]  = i; else leafParent[~leftRef]  = i;
   if (rightRef >= 0) innerParent[rightRef] = i; else leafParent[~rightRef] = i;
   if (i == 0) innerParent[0] = -1;
@@ -163,13 +165,17 @@ TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const 
 }
 
 // One thread per leaf walks up; the second thread to arrive at an inner node (ticket == 1) owns it.
-// leafMode 0: leaf reference = ~(leafBase + sorted position); 1: leaf reference = ~(primitive index).
+// leafMode 0 (triangles): leaf reference = ~(first slot | (count - 1) << 28) with first = leafBase + sorted
+// position; a child subtree that covers at most maxLeaf sorted positions is referenced as ONE leaf (its slots are
+// contiguous because the leaves of a radix tree are in key order), which removes the bottom levels of the tree.
+// leafMode 1 (instances): leaf reference = ~(primitive index), never collapsed.
 __global__ void refitKernel(const unsigned long long* __restrict__ keys, int count,
                             const float4* __restrict__ primLo, const float4* __restrict__ primHi,
                             const int* __restrict__ left, const int* __restrict__ right,
                             const int* __restrict__ innerParent, const int* __restrict__ leafParent,
+                            const int2* __restrict__ range,
                             unsigned int* __restrict__ tickets, float4* nodeLo, float4* nodeHi,
-                            BvhNode* __restrict__ outNodes, int nodeBase, int leafMode, int leafBase)
+                            BvhNode* __restrict__ outNodes, int nodeBase, int leafMode, int leafBase, int maxLeaf)
 {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= count) return;
@@ -194,7 +200,8 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
     else
     {
       lo0 = nodeLo[l]; hi0 = nodeHi[l];
-      c0 = nodeBase + l;
+      const int2 rg = range[l];
+      c0 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28)) : nodeBase + l;
     }
     if (r < 0)
     {
@@ -205,7 +212,8 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
     else
     {
       lo1 = nodeLo[r]; hi1 = nodeHi[r];
-      c1 = nodeBase + r;
+      const int2 rg = range[r];
+      c1 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28)) : nodeBase + r;
     }
     writeNode(&outNodes[node], lo0, hi0, lo1, hi1, c0, c1);
     nodeLo[node] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
@@ -257,6 +265,7 @@ hipError_t BvhBuilder::reserve(int count)
   BVH_CHECK(hipMalloc(&m_right, sizeof(int) * n));
   BVH_CHECK(hipMalloc(&m_innerParent, sizeof(int) * n));
   BVH_CHECK(hipMalloc(&m_leafParent, sizeof(int) * n));
+  BVH_CHECK(hipMalloc(&m_range, sizeof(int2) * n));
   BVH_CHECK(hipMalloc(&m_tickets, sizeof(unsigned int) * n));
   BVH_CHECK(hipMalloc(&m_nodeLo, sizeof(float4) * n));
   BVH_CHECK(hipMalloc(&m_nodeHi, sizeof(float4) * n));
@@ -270,11 +279,11 @@ hipError_t BvhBuilder::reserve(int count)
 
 void BvhBuilder::release()
 {
-  void* p[] = { m_primLo, m_primHi, m_keysIn, m_keysOut, m_left, m_right, m_innerParent, m_leafParent, m_tickets, m_nodeLo, m_nodeHi, m_bounds, m_sortTemp };
+  void* p[] = { m_primLo, m_primHi, m_keysIn, m_keysOut, m_left, m_right, m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, m_bounds, m_sortTemp };
   for (void* q : p) if (q) (void) hipFree(q);
   m_primLo = m_primHi = m_nodeLo = m_nodeHi = nullptr;
   m_keysIn = m_keysOut = nullptr;
-  m_left = m_right = m_innerParent = m_leafParent = nullptr;
+  m_left = m_right = m_innerParent = m_leafParent = nullptr; m_range = nullptr;
   m_tickets = nullptr; m_bounds = nullptr; m_sortTemp = nullptr;
   m_capacity = 0;
 }
@@ -293,9 +302,9 @@ hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* ou
   hipLaunchKernelGGL(mortonKeysKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, count, m_bounds, m_keysIn);
   BVH_CHECK(rocprim::radix_sort_keys(m_sortTemp, m_sortBytes, m_keysIn, m_keysOut, (size_t) count, 0, 64, stream));
   BVH_CHECK(hipMemsetAsync(m_tickets, 0, sizeof(unsigned int) * count, stream));
-  hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent);
+  hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent, m_range);
   hipLaunchKernelGGL(refitKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_primLo, m_primHi, m_left, m_right,
-                     m_innerParent, m_leafParent, m_tickets, m_nodeLo, m_nodeHi, outNodes, nodeBase, leafMode, leafBase);
+                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, nodeBase, leafMode, leafBase, m_maxLeaf);
   return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include "error_state.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -219,8 +220,8 @@ static int ensureStreams(TwkDevice dev)
     freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
     const size_t n = (size_t) numPixels;
     // float4 streams: rayOrg[2], rayDir[2], hitRecord, shadowOrg, shadowDir, shadowPending, throughput, radiance, volumeStack[4] = 14
-    // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel
-    const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 4 * sizeof(unsigned int)) + 4096;
+    // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]
+    const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
     HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
     HIP_TRY(hipMalloc(&dev->d_outputInternal, n * sizeof(float4)));
     HIP_TRY(hipMemsetAsync(dev->d_outputInternal, 0, n * sizeof(float4), dev->stream));
@@ -253,6 +254,7 @@ static int ensureStreams(TwkDevice dev)
   p.rayPixel[0] = (unsigned int*) take(4); p.rayPixel[1] = (unsigned int*) take(4);
   p.hitInstance = (int*) take(4);
   p.shadowPixel = (unsigned int*) take(4);
+  p.overflowSlots = (unsigned int*) take(8);
   return TWK_SUCCESS;
 }
 
@@ -631,6 +633,7 @@ int twk_build(TwkDevice dev)
     HIP_TRY(hipMemcpyAsync(dev->d_indices + g.indexBase, g.indices.data(), sizeof(unsigned int) * g.indices.size(), hipMemcpyHostToDevice, dev->stream));
   }
 
+  if (const char* e = getenv("TWK_MAX_LEAF")) dev->builder.setMaxLeaf(atoi(e)); // tuning knob, default 4 triangles per leaf
   // bottom level: one LBVH per geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
   for (GeometryHost& g : dev->geometries)
   {
@@ -650,6 +653,7 @@ int twk_build(TwkDevice dev)
     memcpy(r.objectToWorld, inst.transform, sizeof(float) * 12);
     invertAffine(inst.transform, r.worldToObject);
     r.blasRoot = g.nodeBase; r.material = inst.material; r.light = inst.light;
+    r.triangleFirst = g.triangleBase; r.triangleCount = g.numTriangles;
     r.attributeBase = g.attributeBase; r.indexBase = g.indexBase; r.geometry = inst.geometry;
 
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};

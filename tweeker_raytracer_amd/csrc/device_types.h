@@ -61,19 +61,25 @@ struct DevLight
   float unused0, unused1, unused2;
 };
 
-// ≙ OptixInstance + hit-group record (src/Device.cpp:1427-1445,1492-1532), 128 B
+// ≙ OptixInstance + hit-group record (src/Device.cpp:1427-1445,1492-1532), 128 B.
+// The first 64 bytes are everything traversal needs (four 16-byte loads); shading reads the rest.
 struct DevInstance
 {
-  float objectToWorld[12];
   float worldToObject[12];
-  int   blasRoot;     // node index of the geometry's BVH root in the shared node array
+  int   blasRoot;      // node index of the geometry's BVH root in the shared node array
+  int   triangleFirst; // first triangle slot of the geometry
+  int   triangleCount; // <= TWK_INLINE_TRIANGLES: traversal tests the triangles right at the top-level leaf
+  int   geometry;
+  float objectToWorld[12];
   int   material;
-  int   light;        // < 0: not a light
+  int   light;         // < 0: not a light
   unsigned int attributeBase; // first TriangleAttributes of the geometry in the shared attribute array
   unsigned int indexBase;     // first index (uint) of the geometry in the shared index array
-  int   geometry;
-  int   pad0, pad1;
 };
+
+// Geometries with at most this many triangles (planes, the light quad, boxes' faces ...) have no bottom-level
+// descent: entering, one node, two leaves and leaving collapse into one step at the top-level leaf.
+#define TWK_INLINE_TRIANGLES 4
 
 struct DevTexture
 {
@@ -84,7 +90,8 @@ struct DevTexture
 };
 
 // BVH2 node, 64 B. Child reference: >= 0 inner node index; < 0 leaf, payload = ~ref:
-// bottom level: triangle slot in the reordered triangle array; top level: instance index.
+// bottom level: bits 0-27 first triangle slot in the reordered triangle array, bits 28-30 triangle count - 1;
+// top level: instance index.
 struct __attribute__((aligned(16))) BvhNode
 {
   float lo0[3]; float hi0x;
@@ -148,12 +155,13 @@ struct LaunchParams
   float4* firstHit;       // debug capture (t, beta, gamma, prim) or nullptr
   int*    firstHitInstance;
   int*    traceStackSpill; // per persistent lane overflow stack
+  unsigned int* overflowSlots; // queue slots of rays that overflowed the LDS stack (2 per launch index)
   int     numPixels;      // launchWidth * height
 };
 
 // Counter block layout (unsigned int each), zeroed once per launch.
 // per depth d (0..maxDepth): [d*4+0] rays in queue d, [d*4+1] shadow rays emitted by shade d,
-// [d*4+2] trace work ticket of trace launch d, [d*4+3] unused
+// [d*4+2] trace work ticket of trace launch d, [d*4+3] rays of trace launch d that overflowed the LDS stack
 #define TWK_COUNTERS_PER_DEPTH 4
 #define TWK_MAX_DEPTH 64
 

@@ -185,43 +185,76 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
     if (currentInstance < 0)
     {
       // top level: enter the instance
-      const DevInstance* inst = p.instances + payload;
+      const float4* rec = reinterpret_cast<const float4*>(p.instances + payload);
+      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
       if (COUNT) ++instCount;
       float m[12];
-      const float4* mw = reinterpret_cast<const float4*>(inst->worldToObject);
-      const float4 r0 = mw[0], r1 = mw[1], r2 = mw[2];
       m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w;
       m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
       m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w;
       objOrg = transformPoint(m, org);
       const V3 objDir = transformVector(m, dir);
-      setupRay(ray, objOrg, objDir);
       woopSetup(objDir, woop);
+      const int triCountInst = __float_as_int(r3.z);
+      if (triCountInst <= TWK_INLINE_TRIANGLES)
+      {
+        // small geometry: test its triangles here, stay in the top level
+        const int first = __float_as_int(r3.y);
+        bool stop = false;
+        for (int slot = first; slot < first + triCountInst; ++slot)
+        {
+          const float4* tri = p.triangles + 3 * (size_t) slot;
+          const float4 a = tri[0], b = tri[1], c = tri[2];
+          if (COUNT) ++triCount;
+          float t, beta, gamma;
+          if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+          {
+            const int prim = __float_as_int(a.w);
+            const bool closer = (t < res.t) ||
+                                (t == res.t && res.instance >= 0 &&
+                                 (payload < res.instance || (payload == res.instance && prim < res.primitive)));
+            if (closer)
+            {
+              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim;
+              if (anyHit) { stop = true; break; }
+            }
+          }
+        }
+        if (stop || sp == 0) break;
+        TWK_POP(node);
+        continue;
+      }
+      setupRay(ray, objOrg, objDir);
       currentInstance = payload;
       TWK_PUSH(TWK_BVH_SENTINEL);
-      node = inst->blasRoot;
+      node = __float_as_int(r3.x);
       continue;
     }
 
-    // bottom level: one triangle slot
+    // bottom level: a leaf of 1..8 consecutive triangle slots
     {
-      const float4* tri = p.triangles + 3 * (size_t) payload;
-      const float4 a = tri[0], b = tri[1], c = tri[2];
-      if (COUNT) ++triCount;
-      float t, beta, gamma;
-      if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+      const int first = payload & 0x0fffffff, last = first + (payload >> 28);
+      bool stop = false;
+      for (int slot = first; slot <= last; ++slot)
       {
-        const int prim = __float_as_int(a.w);
-        const bool closer = (t < res.t) ||
-                            (t == res.t && res.instance >= 0 &&
-                             (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
-        if (closer)
+        const float4* tri = p.triangles + 3 * (size_t) slot;
+        const float4 a = tri[0], b = tri[1], c = tri[2];
+        if (COUNT) ++triCount;
+        float t, beta, gamma;
+        if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
         {
-          res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
-          if (anyHit) break;
+          const int prim = __float_as_int(a.w);
+          const bool closer = (t < res.t) ||
+                              (t == res.t && res.instance >= 0 &&
+                               (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
+          if (closer)
+          {
+            res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
+            if (anyHit) { stop = true; break; }
+          }
         }
       }
-      if (sp == 0) break;
+      if (stop || sp == 0) break;
       TWK_POP(node);
     }
   }
@@ -243,12 +276,14 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
 #define TWK_TRACE_REFILL 44
 
 template<bool COUNT>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, 6) // 6 waves/SIMD = the 6 blocks per CU the 24-KiB LDS stacks admit
+#ifndef TWK_TRACE_WAVES
+#define TWK_TRACE_WAVES 6
+#endif
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // waves/SIMD; the 24-KiB LDS stacks admit 6 blocks per CU
 traceKernel(LaunchParams p, int depth)
 {
   __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
   int* ldsStack = stackStorage + threadIdx.x;
-  int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
   const int stride = TWK_TRACE_BLOCK;
 
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
@@ -287,9 +322,8 @@ traceKernel(LaunchParams p, int depth)
   WoopConstants woop; woop.kx = 0; woop.ky = 1; woop.kz = 2; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
   unsigned int guard = 0;
-
-#define TWK_PUSH(v) do { if (sp < TWK_TRACE_STACK_LDS) ldsStack[sp * stride] = (v); else if (sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) spill[sp - TWK_TRACE_STACK_LDS] = (v); ++sp; } while (0)
-#define TWK_POP(v)  do { --sp; (v) = (sp < TWK_TRACE_STACK_LDS) ? ldsStack[sp * stride] : ((sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) ? spill[sp - TWK_TRACE_STACK_LDS] : TWK_BVH_SENTINEL); } while (0)
+  bool retrace = false; // LDS stack overflow: the ray is re-traced by traceOverflowKernel with the spilling traverse()
+  bool continue_after_overflow = false;
 
   for (;;)
   {
@@ -339,27 +373,36 @@ traceKernel(LaunchParams p, int depth)
     // ---- traverse until enough lanes have finished to be worth a refill ------------------------------
     for (;;)
     {
-      // all lanes descend inner nodes
+      // All lanes descend inner nodes. Kept flat on purpose: the stack lives in LDS only here, push and pop are
+      // straight-line predicated code (nested LDS/HBM stack selects compiled to ~70 scalar branch instructions
+      // per node). A lane whose stack would overflow abandons this traversal and re-traces its ray with the
+      // spilling traverse() (cold path, not taken on the LBVHs of the shipped scenes).
       while (hasRay && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
         const float4* n = reinterpret_cast<const float4*>(p.nodes + node);
         const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        ++guard;
         if (COUNT) ++nodeCount;
         float t0, t1;
         const bool h0 = slabTest(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, res.t, t0);
         const bool h1 = slabTest(ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, res.t, t1);
         const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+        const bool take0 = h0 && (!h1 || t0 <= t1); // child 0 is next: the only hit, or the nearer of two
+        node = take0 ? c0 : c1;
+        bool stop = (guard > (1u << 22));
         if (h0 && h1)
         {
-          const bool firstIs0 = (t0 <= t1);
-          TWK_PUSH(firstIs0 ? c1 : c0);
-          node = firstIs0 ? c0 : c1;
+          retrace = retrace || (sp >= TWK_TRACE_STACK_LDS);
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS - 1) * stride] = take0 ? c1 : c0;
+          ++sp;
         }
-        else if (h0) node = c0;
-        else if (h1) node = c1;
-        else if (sp == 0) { hasRay = false; done = true; } // traversal complete, result written below
-        else TWK_POP(node);
-        if (++guard > (1u << 22)) { hasRay = false; done = true; }
+        if (!(h0 || h1))
+        {
+          stop = stop || (sp == 0);
+          sp = max(sp - 1, 0);
+          node = ldsStack[sp * stride];
+        }
+        if (stop || retrace) { hasRay = false; done = true; }
       }
 
       // one leaf / instance-entry / instance-exit step per lane
@@ -377,39 +420,75 @@ traceKernel(LaunchParams p, int depth)
           const int payload = ~node;
           if (currentInstance < 0)
           {
-            const DevInstance* inst = p.instances + payload;
+            const float4* rec = reinterpret_cast<const float4*>(p.instances + payload);
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             if (COUNT) ++instCount;
             float m[12];
-            const float4* mw = reinterpret_cast<const float4*>(inst->worldToObject);
-            const float4 r0 = mw[0], r1 = mw[1], r2 = mw[2];
             m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w;
             m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
             m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w;
             const V3 objOrg = transformPoint(m, org);
             const V3 objDir = transformVector(m, dir);
-            setupRay(ray, objOrg, objDir);
             woopSetup(objDir, woop);
-            currentInstance = payload;
-            TWK_PUSH(TWK_BVH_SENTINEL);
-            node = inst->blasRoot;
+            const int triCountInst = __float_as_int(r3.z);
+            if (triCountInst <= TWK_INLINE_TRIANGLES)
+            {
+              // small geometry: test its triangles here, stay in the top level (no descent, no sentinel)
+              const int first = __float_as_int(r3.y);
+              pop = true;
+              for (int ts = first; ts < first + triCountInst; ++ts)
+              {
+                const float4* tri = p.triangles + 3 * (size_t) ts;
+                const float4 a = tri[0], b = tri[1], c = tri[2];
+                if (COUNT) ++triCount;
+                float t, beta, gamma;
+                if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+                {
+                  const int prim = __float_as_int(a.w);
+                  const bool closer = (t < res.t) ||
+                                      (t == res.t && res.instance >= 0 &&
+                                       (payload < res.instance || (payload == res.instance && prim < res.primitive)));
+                  if (closer)
+                  {
+                    res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim;
+                    if (anyHit) { pop = false; hasRay = false; done = true; break; }
+                  }
+                }
+              }
+            }
+            else
+            {
+              setupRay(ray, objOrg, objDir);
+              currentInstance = payload;
+              retrace = retrace || (sp >= TWK_TRACE_STACK_LDS);
+              ldsStack[min(sp, TWK_TRACE_STACK_LDS - 1) * stride] = TWK_BVH_SENTINEL;
+              ++sp;
+              node = __float_as_int(r3.x);
+              if (retrace) { hasRay = false; done = true; }
+            }
           }
           else
           {
-            const float4* tri = p.triangles + 3 * (size_t) payload;
-            const float4 a = tri[0], b = tri[1], c = tri[2];
-            if (COUNT) ++triCount;
-            float t, beta, gamma;
+            // a leaf of 1..8 consecutive triangle slots
+            const int first = payload & 0x0fffffff, last = first + (payload >> 28);
             pop = true;
-            if (woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+            for (int ts = first; ts <= last; ++ts)
             {
-              const int prim = __float_as_int(a.w);
-              const bool closer = (t < res.t) ||
-                                  (t == res.t && res.instance >= 0 &&
-                                   (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
-              if (closer)
+              const float4* tri = p.triangles + 3 * (size_t) ts;
+              const float4 a = tri[0], b = tri[1], c = tri[2];
+              if (COUNT) ++triCount;
+              float t, beta, gamma;
+              if (woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
               {
-                res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
-                if (anyHit) { pop = false; hasRay = false; done = true; }
+                const int prim = __float_as_int(a.w);
+                const bool closer = (t < res.t) ||
+                                    (t == res.t && res.instance >= 0 &&
+                                     (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
+                if (closer)
+                {
+                  res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
+                  if (anyHit) { pop = false; hasRay = false; done = true; break; }
+                }
               }
             }
           }
@@ -417,7 +496,7 @@ traceKernel(LaunchParams p, int depth)
         if (pop)
         {
           if (sp == 0) { hasRay = false; done = true; }
-          else TWK_POP(node);
+          else { --sp; node = ldsStack[sp * stride]; }
         }
       }
 
@@ -425,8 +504,18 @@ traceKernel(LaunchParams p, int depth)
       if (done)
       {
         done = false;
+        if (retrace)
+        {
+          // LDS stack overflow: hand the ray to traceOverflowKernel (spilling single-ray traversal), which runs
+          // right behind this launch; nothing is written for it here.
+          retrace = false;
+          const unsigned int k = atomicAdd(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3], 1u);
+          p.overflowSlots[k] = slot;
+          continue_after_overflow = true;
+        }
         if (COUNT) maxSteps = max(maxSteps, guard);
-        if (!anyHit)
+        if (continue_after_overflow) { continue_after_overflow = false; }
+        else if (!anyHit)
         {
           p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
           p.hitInstance[slot] = res.instance;
@@ -459,8 +548,6 @@ traceKernel(LaunchParams p, int depth)
       if (!exhausted && __popcll(active) < min(TWK_TRACE_REFILL, (int) ticketSize)) break;
     }
   }
-#undef TWK_PUSH
-#undef TWK_POP
 
   if (COUNT)
   {
@@ -470,6 +557,64 @@ traceKernel(LaunchParams p, int depth)
     atomicAdd(&p.stats[3], (unsigned long long) triCount);
     atomicAdd(&p.stats[4], (unsigned long long) instCount);
     atomicMax(&p.stats[7], (unsigned long long) maxSteps);
+  }
+}
+
+// Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again
+// with the single-ray traversal whose stack continues in HBM. Launched behind every traceKernel; exits at once when
+// the list is empty.
+template<bool COUNT>
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK)
+traceOverflowKernel(LaunchParams p, int depth)
+{
+  __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
+  const unsigned int count = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3];
+  if (count == 0u) return;
+  int* ldsStack = stackStorage + threadIdx.x;
+  int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
+  const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
+  const int q = depth & 1;
+  unsigned int nodeCount = 0, triCount = 0, instCount = 0;
+  for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+  {
+    const unsigned int slot = p.overflowSlots[k];
+    TraceResult res;
+    if (slot < numClosest)
+    {
+      const float4 o = p.rayOrg[q][slot];
+      const float4 d = p.rayDir[q][slot];
+      traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, false, ldsStack, spill, res, nodeCount, triCount, instCount);
+      p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+      p.hitInstance[slot] = res.instance;
+      if (p.firstHit != nullptr && depth == 0)
+      {
+        const unsigned int pixel = p.rayPixel[q][slot];
+        p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+        p.firstHitInstance[pixel] = res.instance;
+      }
+    }
+    else
+    {
+      const unsigned int sIdx = slot - numClosest;
+      const float4 o = p.shadowOrg[sIdx];
+      const float4 d = p.shadowDir[sIdx];
+      traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, true, ldsStack, spill, res, nodeCount, triCount, instCount);
+      if (res.instance < 0)
+      {
+        const unsigned int pixel = p.shadowPixel[sIdx];
+        const float4 c = p.shadowPending[sIdx];
+        float4 r = p.pathRadiance[pixel];
+        r.x += c.x; r.y += c.y; r.z += c.z;
+        p.pathRadiance[pixel] = r;
+      }
+    }
+  }
+  if (COUNT)
+  {
+    // the persistent kernel already counted these rays and its partial visits; add the re-trace's visits
+    atomicAdd(&p.stats[2], (unsigned long long) nodeCount);
+    atomicAdd(&p.stats[3], (unsigned long long) triCount);
+    atomicAdd(&p.stats[4], (unsigned long long) instCount);
   }
 }
 
@@ -504,6 +649,9 @@ void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, h
 {
   if (count) hipLaunchKernelGGL(traceKernel<true>,  dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
   else       hipLaunchKernelGGL(traceKernel<false>, dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
+  if (count) hipLaunchKernelGGL(traceOverflowKernel<true>,  dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  else       hipLaunchKernelGGL(traceOverflowKernel<false>, dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
 }
 
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream)
