@@ -131,7 +131,11 @@ typedef struct TwkLaunchStats
   uint64_t instancesEntered;
   uint64_t shadedHits;
   uint64_t missed;
-  uint64_t maxNodesPerRay;  /* longest single traversal (inner-node visits) seen */
+  uint64_t maxNodesPerRay;  /* longest single traversal (inner-node visits) seen by the wavefront trace kernel */
+  uint64_t tailRays;        /* rays (both kinds) traced inside the tail kernel; not included in the fields above */
+  uint64_t tailNodesVisited;
+  uint64_t tailTrianglesTested;
+  uint64_t tailInstancesEntered;
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */
@@ -141,7 +145,8 @@ enum
   TWK_KERNEL_TRACE    = 1,
   TWK_KERNEL_SHADE    = 2,
   TWK_KERNEL_ACCUM    = 3,
-  TWK_KERNEL_COUNT    = 4
+  TWK_KERNEL_TAIL     = 4,  /* deep bounces in one persistent kernel (trace + shade per lane) */
+  TWK_KERNEL_COUNT    = 5
 };
 
 typedef struct TwkDevice_t* TwkDevice;
@@ -189,6 +194,10 @@ int twk_clear_scene(TwkDevice dev);
  * (raygeneration.cu:246-253), RGBA32F, alpha 1. */
 int twk_launch(TwkDevice dev, unsigned int iterationIndex);
 int twk_sync(TwkDevice dev);                                  /* ≙ Device::synchronizeStream */
+/* twk_launch is asynchronous and deferred: consecutive iteration indices are rendered together, up to `iterations`
+ * samples per pixel per wavefront pass (default 4), as soon as the batch is full or any other call observes the
+ * device. The image is bit-identical to one pass per iteration; 1 restores strict one-launch-per-call behaviour. */
+int twk_set_launch_batch(TwkDevice dev, int iterations);
 
 /* Output. With distribution 0 the buffer is W×H (≙ outputBuffer); with distribution 1 it is the
  * packed launchWidth×H local tile buffer (≙ texelBuffer, DeviceMultiGPULocalCopy.cpp:109-172). */

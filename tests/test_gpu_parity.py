@@ -158,6 +158,25 @@ def test_launch_is_deterministic_and_restartable(twk):
     dev.close()
 
 
+def test_launch_batching_does_not_change_the_image(twk):
+    """twk_launch is deferred: 1, 3 or 4 iterations per wavefront pass, a non-consecutive iteration index in between
+    and a restart must give the same bits as one pass per iteration."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (192, 108))
+    imgs = []
+    for batch in (1, 3, 4):
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        app.initDevice(dev)
+        dev.setLaunchBatch(batch)
+        for it in (0, 1, 2, 3, 4, 5, 6):
+            dev.render(it)
+        dev.render(0)  # restart: iteration 0 overwrites
+        dev.render(1)
+        dev.render(7)  # gap in the iteration index: folded with weight 1/8 exactly as the reference would
+        imgs.append(dev.getOutputBufferHost())
+        dev.close()
+    assert np.array_equal(_bits(imgs[0]), _bits(imgs[1])) and np.array_equal(_bits(imgs[0]), _bits(imgs[2]))
+
+
 def test_tiled_equals_single_device(twk):
     """Tile-interleaved distribution (raygeneration.cu:152-164): N device handles on one GPU, each renders its
     checkerboard share into a packed launchWidth x H buffer; compositing them equals the single-device image."""

@@ -25,6 +25,7 @@ namespace twk {
 void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream);
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream);
 void launchGenerate(const LaunchParams& p, hipStream_t stream);
+void launchTail(const LaunchParams& p, int depth0, bool count, int gridBlocks, hipStream_t stream);
 void launchShade(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream);
 void launchAccumulate(const LaunchParams& p, hipStream_t stream);
 void launchCompositor(const float4* tiles, float4* output, int width, int height, int launchWidth, int deviceCount,
@@ -110,17 +111,27 @@ struct TwkDevice_t
   bool statsEnabled = false;
   bool profileEnabled = false;
   std::vector<TimedLaunch> timed; size_t timedUsed = 0;
-  float profileMs[TWK_KERNEL_COUNT] = {0, 0, 0, 0};
-  int   profileLaunches[TWK_KERNEL_COUNT] = {0, 0, 0, 0};
+  float profileMs[TWK_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int   profileLaunches[TWK_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int   tailDepth = 0; // > 0: bounces >= tailDepth run in the tail kernel (TWK_TAIL_DEPTH); measured no faster than the wavefront at 1920x1080, kept off
+  // Deferred launches: twk_launch only records the iteration; consecutive iterations are rendered together as one
+  // wavefront pass of up to batchMax samples per pixel when the batch is full or anything observes the device.
+  int   batchMax = 4;
+  unsigned int pendingFirst = 0;
+  int   pendingCount = 0;
+  int   allocatedPaths = 0;
 
   LaunchParams params;
   BvhBuilder builder;
 };
 
-static int activate(TwkDevice dev, const char* where)
+static int flushPending(TwkDevice dev);
+
+static int activate(TwkDevice dev, const char* where, bool flush = true)
 {
   if (!dev) return twkSetError(TWK_ERROR_INVALID_VALUE, std::string(where) + ": NULL device handle");
   HIP_TRY(hipSetDevice(dev->ordinal));
+  if (flush && dev->pendingCount > 0) return flushPending(dev); // recorded launches run before anything else touches the device
   return TWK_SUCCESS;
 }
 
@@ -200,6 +211,8 @@ static void refreshParams(TwkDevice dev)
   p.sceneEpsilon = dev->state.epsilonFactor * SCENE_EPSILON_SCALE;
   p.envRotation  = dev->state.envRotation;
   p.numPixels = dev->launchWidth * dev->state.resolution[1];
+  p.batchCount = 1;
+  p.numPaths = p.numPixels;
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   p.counters = dev->d_counters;
   p.stats = dev->statsEnabled ? dev->d_stats : nullptr;
@@ -213,24 +226,30 @@ static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * 6; } // 24 KiB 
 static int ensureStreams(TwkDevice dev)
 {
   const int numPixels = dev->launchWidth * dev->state.resolution[1];
-  if (numPixels > dev->allocatedPixels || dev->d_streamBlock == nullptr)
+  const int numPaths  = numPixels * (dev->batchMax > 1 ? dev->batchMax : 1);
+  if (numPixels > dev->allocatedPixels || dev->d_outputInternal == nullptr)
   {
-    freeDevice(dev->d_streamBlock);
     freeDevice(dev->d_outputInternal);
     freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
     const size_t n = (size_t) numPixels;
-    // float4 streams: rayOrg[2], rayDir[2], hitRecord, shadowOrg, shadowDir, shadowPending, throughput, radiance, volumeStack[4] = 14
-    // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]
-    const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
-    HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
     HIP_TRY(hipMalloc(&dev->d_outputInternal, n * sizeof(float4)));
     HIP_TRY(hipMemsetAsync(dev->d_outputInternal, 0, n * sizeof(float4), dev->stream));
     HIP_TRY(hipMalloc(&dev->d_firstHit, n * sizeof(float4)));
     HIP_TRY(hipMalloc(&dev->d_firstHitInstance, n * sizeof(int)));
     dev->allocatedPixels = numPixels;
   }
+  if (numPaths > dev->allocatedPaths || dev->d_streamBlock == nullptr)
+  {
+    freeDevice(dev->d_streamBlock);
+    const size_t n = (size_t) numPaths;
+    // float4 streams: rayOrg[2], rayDir[2], hitRecord, shadowOrg, shadowDir, shadowPending, throughput, radiance, volumeStack[4] = 14
+    // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]
+    const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
+    HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
+    dev->allocatedPaths = numPaths;
+  }
   if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
-  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 8)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 8, dev->stream)); }
+  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 16)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 16, dev->stream)); }
   const size_t lanes = (size_t) traceGridBlocks(dev) * TWK_TRACE_BLOCK;
   if (lanes > dev->spillLanes)
   {
@@ -241,7 +260,7 @@ static int ensureStreams(TwkDevice dev)
 
   // carve the block
   LaunchParams& p = dev->params;
-  const size_t n = (size_t) dev->allocatedPixels;
+  const size_t n = (size_t) dev->allocatedPaths;
   char* base = static_cast<char*>(dev->d_streamBlock);
   auto take = [&](size_t elemBytes) { char* r = base; base += n * elemBytes; return r; };
   p.rayOrg[0] = (float4*) take(16); p.rayOrg[1] = (float4*) take(16);
@@ -353,6 +372,50 @@ static void calculateSphericalCDF(const float* rgba, unsigned int width, unsigne
   else                  { for (unsigned int y = 1; y <= height; ++y) cdfV[y] = float(y) / float(height); }
 }
 
+// Runs the recorded iterations [pendingFirst, pendingFirst + pendingCount) as one wavefront pass.
+static int flushPending(TwkDevice dev)
+{
+  int rc;
+  if ((rc = ensureStreams(dev))) return rc;
+  refreshParams(dev);
+  LaunchParams& p = dev->params;
+  p.iterationIndex = dev->pendingFirst;
+  p.batchCount = dev->pendingCount;
+  p.numPaths = p.numPixels * p.batchCount;
+  dev->pendingCount = 0;
+
+  const int maxDepth = dev->state.pathLengths[1];
+  HIP_TRY(hipMemsetAsync(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2), dev->stream));
+
+  const int traceGrid = traceGridBlocks(dev);
+  int shadeGrid = (p.numPaths + 255) / 256;
+  if (shadeGrid > dev->numCUs * 8) shadeGrid = dev->numCUs * 8;
+
+  // Bounces [0, wavefrontDepth) run as per-depth trace/shade launches over compacted queues; the remaining bounces
+  // of every surviving path run inside one persistent tail kernel (tail_kernel.hip).
+  int wavefrontDepth = maxDepth;
+  if (dev->tailDepth > 0 && dev->tailDepth < maxDepth) wavefrontDepth = dev->tailDepth;
+
+  timedLaunchBegin(dev, TWK_KERNEL_GENERATE); launchGenerate(p, dev->stream); timedLaunchEnd(dev);
+  for (int depth = 0; depth < wavefrontDepth; ++depth)
+  {
+    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, depth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
+    timedLaunchBegin(dev, TWK_KERNEL_SHADE); launchShade(p, depth, shadeGrid, dev->stream); timedLaunchEnd(dev);
+  }
+  if (maxDepth > 0)
+  {
+    // closest hits of queue `wavefrontDepth` (empty when wavefrontDepth == maxDepth) + the shadow rays of the last shade
+    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, wavefrontDepth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
+  }
+  if (wavefrontDepth < maxDepth)
+  {
+    timedLaunchBegin(dev, TWK_KERNEL_TAIL); launchTail(p, wavefrontDepth, dev->statsEnabled, dev->numCUs * 3, dev->stream); timedLaunchEnd(dev);
+  }
+  timedLaunchBegin(dev, TWK_KERNEL_ACCUM); launchAccumulate(p, dev->stream); timedLaunchEnd(dev);
+  HIP_TRY(hipGetLastError());
+  return TWK_SUCCESS;
+}
+
 // =============================================================================================
 extern "C" {
 
@@ -402,6 +465,8 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
     return twkSetError(TWK_ERROR_NO_DEVICE, std::string("twk_device_create: ") + hipGetErrorString(err));
   }
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
+  if (const char* e = getenv("TWK_BATCH")) { const int b = atoi(e); dev->batchMax = (b < 1) ? 1 : ((b > 16) ? 16 : b); }
   *out = dev;
   return TWK_SUCCESS;
 }
@@ -409,6 +474,7 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
 int twk_device_destroy(TwkDevice dev)
 {
   if (!dev) return TWK_SUCCESS;
+  dev->pendingCount = 0; // recorded but never observed launches are dropped
   (void) hipSetDevice(dev->ordinal);
   if (dev->stream) (void) hipStreamSynchronize(dev->stream);
   for (TimedLaunch& t : dev->timed) { (void) hipEventDestroy(t.start); (void) hipEventDestroy(t.stop); }
@@ -568,7 +634,7 @@ int twk_clear_scene(TwkDevice dev)
 int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, size_t numAttributes,
                      const unsigned int* indices, size_t numIndices, int* idGeometry)
 {
-  if (!dev) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: NULL device handle");
+  int rc = activate(dev, "twk_add_geometry"); if (rc) return rc;
   if (!attributes || !indices || numAttributes == 0 || numIndices == 0 || (numIndices % 3) != 0)
     return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: need attributes and a non-empty multiple of three indices");
   for (size_t i = 0; i < numIndices; ++i)
@@ -585,7 +651,7 @@ int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, siz
 
 int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12], int idMaterial, int idLight, int* idInstance)
 {
-  if (!dev) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: NULL device handle");
+  int rc = activate(dev, "twk_add_instance"); if (rc) return rc;
   if (!transform || idGeometry < 0 || idGeometry >= (int) dev->geometries.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: bad geometry id");
   if (idMaterial < 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: an instance needs a material (Device.cpp:1429)");
   InstanceHost inst;
@@ -685,7 +751,7 @@ int twk_build(TwkDevice dev)
 
 int twk_launch(TwkDevice dev, unsigned int iterationIndex)
 {
-  int rc = activate(dev, "twk_launch"); if (rc) return rc;
+  int rc = activate(dev, "twk_launch", false); if (rc) return rc;
   if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: twk_set_state has not been called (samplesSqrt 0, Device.cpp:293)");
   if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: twk_build has not been called");
   if (dev->cameras.empty() || dev->materials.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: cameras and materials are required");
@@ -693,31 +759,25 @@ int twk_launch(TwkDevice dev, unsigned int iterationIndex)
   for (const DevMaterial& m : dev->materials)
     if (m.textureAlbedo && dev->d_texels[TWK_TEXTURE_ALBEDO] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: a material uses the albedo texture but none was uploaded");
 
-  if ((rc = ensureStreams(dev))) return rc;
-  refreshParams(dev);
-  LaunchParams& p = dev->params;
-  p.iterationIndex = iterationIndex;
-
-  const int maxDepth = dev->state.pathLengths[1];
-  HIP_TRY(hipMemsetAsync(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (maxDepth + 2), dev->stream));
-
-  const int traceGrid = traceGridBlocks(dev);
-  int shadeGrid = (p.numPixels + 255) / 256;
-  if (shadeGrid > dev->numCUs * 8) shadeGrid = dev->numCUs * 8;
-
-  timedLaunchBegin(dev, TWK_KERNEL_GENERATE); launchGenerate(p, dev->stream); timedLaunchEnd(dev);
-  for (int depth = 0; depth < maxDepth; ++depth)
+  // Asynchronous like optixLaunch: the iteration is recorded; consecutive iterations are rendered together (up to
+  // batchMax samples per pixel per wavefront pass). Results are identical to one pass per iteration.
+  const int limit = dev->captureFirstHits ? 1 : (dev->batchMax > 1 ? dev->batchMax : 1);
+  if (dev->pendingCount > 0 && (iterationIndex != dev->pendingFirst + (unsigned int) dev->pendingCount || dev->pendingCount >= limit))
   {
-    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, depth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
-    timedLaunchBegin(dev, TWK_KERNEL_SHADE); launchShade(p, depth, shadeGrid, dev->stream); timedLaunchEnd(dev);
+    if ((rc = flushPending(dev))) return rc;
   }
-  if (maxDepth > 0)
-  {
-    // shadow rays of the last bounce
-    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, maxDepth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
-  }
-  timedLaunchBegin(dev, TWK_KERNEL_ACCUM); launchAccumulate(p, dev->stream); timedLaunchEnd(dev);
-  HIP_TRY(hipGetLastError());
+  if (dev->pendingCount == 0) dev->pendingFirst = iterationIndex;
+  dev->pendingCount++;
+  if (dev->pendingCount >= limit) return flushPending(dev);
+  return TWK_SUCCESS;
+}
+
+int twk_set_launch_batch(TwkDevice dev, int iterations)
+{
+  int rc = activate(dev, "twk_set_launch_batch"); if (rc) return rc;
+  if (iterations < 1 || iterations > 16) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_launch_batch: 1..16 iterations per pass");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->batchMax = iterations;
   return TWK_SUCCESS;
 }
 
@@ -821,10 +881,11 @@ int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
   memset(stats, 0, sizeof(*stats));
   if (!dev->d_stats) return TWK_SUCCESS;
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  unsigned long long h[8];
+  unsigned long long h[16];
   HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
+  stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }

@@ -148,7 +148,7 @@ struct LaunchParams
   float4* pathThroughput; // xyz throughput, w pdf
   float4* pathRadiance;
   uint2*  pathSeedFlags;
-  float4* volumeStack;    // [4][numPixels]
+  float4* volumeStack;    // [4][numPaths]
   float4* output;         // running mean, RGBA32F
   unsigned int* counters; // see CounterSlot
   unsigned long long* stats; // TwkLaunchStats as 7 u64, or nullptr
@@ -156,7 +156,9 @@ struct LaunchParams
   int*    firstHitInstance;
   int*    traceStackSpill; // per persistent lane overflow stack
   unsigned int* overflowSlots; // queue slots of rays that overflowed the LDS stack (2 per launch index)
-  int     numPixels;      // launchWidth * height
+  int     numPixels;      // launchWidth * height = launch indices of ONE sample per pixel
+  int     numPaths;       // numPixels * batchCount: paths of this wavefront pass, path = sample * numPixels + launch index
+  int     batchCount;     // iterations rendered together (iterationIndex .. iterationIndex + batchCount - 1)
 };
 
 // Counter block layout (unsigned int each), zeroed once per launch.

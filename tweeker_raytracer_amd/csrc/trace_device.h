@@ -1,0 +1,256 @@
+// Device functions of ray traversal, shared by trace_kernels.hip and tail_kernel.hip: conservative slab test,
+// watertight triangle test (Woop, Benthin, Wald, JCGT 2013), and the single-ray two-level traversal whose stack
+// continues from LDS into HBM. See trace_kernels.hip for the contract these stand in for (optixTrace).
+#pragma once
+#include "device_types.h"
+
+namespace twk {
+
+
+struct TraceRay
+{
+  V3 o, d, id, ood; // origin, direction, guarded reciprocal direction, origin * reciprocal direction
+};
+
+TWK_D float guardedReciprocal(float d)
+{
+  // Parallel-to-slab rays: a huge finite reciprocal keeps 0 * inf = NaN out of the slab test and
+  // makes "origin on the slab plane" count as inside (conservative).
+  return (fabsf(d) >= 1.0e-20f) ? 1.0f / d : copysignf(1.0e20f, d);
+}
+
+TWK_D void setupRay(TraceRay& r, const V3& o, const V3& d)
+{
+  r.o = o; r.d = d;
+  r.id  = v3(guardedReciprocal(d.x), guardedReciprocal(d.y), guardedReciprocal(d.z));
+  r.ood = v3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
+}
+
+// Conservative slab test of one child box: plane distances as one fused multiply-add each (the box test only
+// culls, its rounding is not part of the result; the 2.5e-6 relative widening covers fma-vs-exact differences,
+// and boxes are padded at build time). Returns the entry distance for near/far ordering.
+TWK_D bool slabTest(const TraceRay& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float tmax, float& tnear)
+{
+  const float x0 = __builtin_fmaf(lox, r.id.x, -r.ood.x), x1 = __builtin_fmaf(hix, r.id.x, -r.ood.x);
+  const float y0 = __builtin_fmaf(loy, r.id.y, -r.ood.y), y1 = __builtin_fmaf(hiy, r.id.y, -r.ood.y);
+  const float z0 = __builtin_fmaf(loz, r.id.z, -r.ood.z), z1 = __builtin_fmaf(hiz, r.id.z, -r.ood.z);
+  const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+  tnear = tn;
+  return tn * 0.9999975f <= tf * 1.0000025f;
+}
+
+struct WoopConstants
+{
+  int   kx, ky, kz;
+  float Sx, Sy, Sz;
+};
+
+TWK_D float component(const V3& v, int k) { return (k == 0) ? v.x : ((k == 1) ? v.y : v.z); }
+
+TWK_D void woopSetup(const V3& d, WoopConstants& w)
+{
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  int kx = (kz == 2) ? 0 : kz + 1;
+  int ky = (kx == 2) ? 0 : kx + 1;
+  const float dz = component(d, kz);
+  if (dz < 0.0f) { const int s = kx; kx = ky; ky = s; }
+  w.kx = kx; w.ky = ky; w.kz = kz;
+  w.Sx = component(d, kx) / dz;
+  w.Sy = component(d, ky) / dz;
+  w.Sz = 1.0f / dz;
+}
+
+TWK_D bool woopIntersect(const WoopConstants& w, const V3& o, const V3& p0, const V3& p1, const V3& p2,
+                         float tmin, float& t, float& beta, float& gamma)
+{
+  const V3 A = p0 - o, B = p1 - o, C = p2 - o;
+  const float Akx = component(A, w.kx), Aky = component(A, w.ky), Akz = component(A, w.kz);
+  const float Bkx = component(B, w.kx), Bky = component(B, w.ky), Bkz = component(B, w.kz);
+  const float Ckx = component(C, w.kx), Cky = component(C, w.ky), Ckz = component(C, w.kz);
+
+  const float Ax = Akx - w.Sx * Akz, Ay = Aky - w.Sy * Akz;
+  const float Bx = Bkx - w.Sx * Bkz, By = Bky - w.Sy * Bkz;
+  const float Cx = Ckx - w.Sx * Ckz, Cy = Cky - w.Sy * Ckz;
+
+  float U = Cx * By - Cy * Bx;
+  float V = Ax * Cy - Ay * Cx;
+  float W = Bx * Ay - By * Ax;
+
+  if (U == 0.0f || V == 0.0f || W == 0.0f)
+  {
+    const double CxBy = (double) Cx * (double) By, CyBx = (double) Cy * (double) Bx;
+    U = (float) (CxBy - CyBx);
+    const double AxCy = (double) Ax * (double) Cy, AyCx = (double) Ay * (double) Cx;
+    V = (float) (AxCy - AyCx);
+    const double BxAy = (double) Bx * (double) Ay, ByAx = (double) By * (double) Ax;
+    W = (float) (BxAy - ByAx);
+  }
+
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+
+  const float det = U + V + W;
+  if (det == 0.0f) return false;
+
+  const float Az = w.Sz * Akz, Bz = w.Sz * Bkz, Cz = w.Sz * Ckz;
+  const float T = U * Az + V * Bz + W * Cz;
+  const float rcpDet = 1.0f / det;
+  const float tt = T * rcpDet;
+  if (!(tt > tmin)) return false;
+
+  t     = tt;
+  beta  = V * rcpDet;
+  gamma = W * rcpDet;
+  return true;
+}
+
+struct TraceResult
+{
+  float t, beta, gamma;
+  int   instance, primitive;
+};
+
+// COUNT: tally node / triangle / instance visits (measurement builds only).
+template<bool COUNT>
+TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float tmin, float tmax, bool anyHit,
+                    int* ldsStack /* [entry * blockDim + tid] base at tid */, int* spill, TraceResult& res,
+                    unsigned int& nodeCount, unsigned int& triCount, unsigned int& instCount)
+{
+  const int stride = TWK_TRACE_BLOCK;
+  res.t = tmax; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1;
+
+  TraceRay ray;
+  setupRay(ray, org, dir);
+  WoopConstants woop;
+  V3 objOrg = org;
+  int currentInstance = -1;
+
+  int sp = 0;
+  int node = p.tlasRoot;
+  unsigned int guard = 0; // a well-formed tree never gets near this; keeps a corrupted one from hanging the GPU
+
+#define TWK_PUSH(v) do { if (sp < TWK_TRACE_STACK_LDS) ldsStack[sp * stride] = (v); else if (sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) spill[sp - TWK_TRACE_STACK_LDS] = (v); ++sp; } while (0)
+#define TWK_POP(v)  do { --sp; (v) = (sp < TWK_TRACE_STACK_LDS) ? ldsStack[sp * stride] : ((sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) ? spill[sp - TWK_TRACE_STACK_LDS] : TWK_BVH_SENTINEL); } while (0)
+
+  for (;;)
+  {
+    if (++guard > (1u << 22)) break;
+    if (node == TWK_BVH_SENTINEL)
+    {
+      // leaving an instance: back to the world-space ray
+      setupRay(ray, org, dir);
+      currentInstance = -1;
+      if (sp == 0) break;
+      TWK_POP(node);
+      continue;
+    }
+
+    if (node >= 0)
+    {
+      const float4* n = reinterpret_cast<const float4*>(p.nodes + node);
+      const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+      if (COUNT) ++nodeCount;
+      float t0, t1;
+      const bool h0 = slabTest(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, res.t, t0);
+      const bool h1 = slabTest(ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, res.t, t1);
+      const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+      if (h0 && h1)
+      {
+        const bool firstIs0 = (t0 <= t1);
+        TWK_PUSH(firstIs0 ? c1 : c0);
+        node = firstIs0 ? c0 : c1;
+      }
+      else if (h0) node = c0;
+      else if (h1) node = c1;
+      else
+      {
+        if (sp == 0) break;
+        TWK_POP(node);
+      }
+      continue;
+    }
+
+    // leaf
+    const int payload = ~node;
+    if (currentInstance < 0)
+    {
+      // top level: enter the instance
+      const float4* rec = reinterpret_cast<const float4*>(p.instances + payload);
+      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+      if (COUNT) ++instCount;
+      float m[12];
+      m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w;
+      m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
+      m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w;
+      objOrg = transformPoint(m, org);
+      const V3 objDir = transformVector(m, dir);
+      woopSetup(objDir, woop);
+      const int triCountInst = __float_as_int(r3.z);
+      if (triCountInst <= TWK_INLINE_TRIANGLES)
+      {
+        // small geometry: test its triangles here, stay in the top level
+        const int first = __float_as_int(r3.y);
+        bool stop = false;
+        for (int slot = first; slot < first + triCountInst; ++slot)
+        {
+          const float4* tri = p.triangles + 3 * (size_t) slot;
+          const float4 a = tri[0], b = tri[1], c = tri[2];
+          if (COUNT) ++triCount;
+          float t, beta, gamma;
+          if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+          {
+            const int prim = __float_as_int(a.w);
+            const bool closer = (t < res.t) ||
+                                (t == res.t && res.instance >= 0 &&
+                                 (payload < res.instance || (payload == res.instance && prim < res.primitive)));
+            if (closer)
+            {
+              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim;
+              if (anyHit) { stop = true; break; }
+            }
+          }
+        }
+        if (stop || sp == 0) break;
+        TWK_POP(node);
+        continue;
+      }
+      setupRay(ray, objOrg, objDir);
+      currentInstance = payload;
+      TWK_PUSH(TWK_BVH_SENTINEL);
+      node = __float_as_int(r3.x);
+      continue;
+    }
+
+    // bottom level: a leaf of 1..8 consecutive triangle slots
+    {
+      const int first = payload & 0x0fffffff, last = first + (payload >> 28);
+      bool stop = false;
+      for (int slot = first; slot <= last; ++slot)
+      {
+        const float4* tri = p.triangles + 3 * (size_t) slot;
+        const float4 a = tri[0], b = tri[1], c = tri[2];
+        if (COUNT) ++triCount;
+        float t, beta, gamma;
+        if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+        {
+          const int prim = __float_as_int(a.w);
+          const bool closer = (t < res.t) ||
+                              (t == res.t && res.instance >= 0 &&
+                               (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
+          if (closer)
+          {
+            res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
+            if (anyHit) { stop = true; break; }
+          }
+        }
+      }
+      if (stop || sp == 0) break;
+      TWK_POP(node);
+    }
+  }
+#undef TWK_PUSH
+#undef TWK_POP
+}
+
+} // namespace twk

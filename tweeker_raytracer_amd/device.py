@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 
-KERNEL_CLASSES = ("generate", "trace", "shade", "accumulate")
+KERNEL_CLASSES = ("generate", "trace", "shade", "accumulate", "tail")
 
 
 def device_count():
@@ -113,6 +113,10 @@ class Device:
         """≙ Device::render(iterationIndex, buffer) → optixLaunch: asynchronous, one sample per pixel."""
         L.check(L.lib.twk_launch(self._h, C.c_uint(int(iterationIndex))))
 
+    def setLaunchBatch(self, iterations):
+        """Iterations rendered together per wavefront pass (1..16); results do not depend on it."""
+        L.check(L.lib.twk_set_launch_batch(self._h, int(iterations)))
+
     def synchronizeStream(self):
         L.check(L.lib.twk_sync(self._h))
 
@@ -148,8 +152,8 @@ class Device:
         L.check(L.lib.twk_profile_reset(self._h))
 
     def profileGet(self):
-        ms = (C.c_float * 4)()
-        n = (C.c_int * 4)()
+        ms = (C.c_float * len(KERNEL_CLASSES))()
+        n = (C.c_int * len(KERNEL_CLASSES))()
         L.check(L.lib.twk_profile_get(self._h, ms, n))
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(KERNEL_CLASSES)}
 
