@@ -11,9 +11,9 @@ public:
 
   // Bottom level over the triangles of one geometry. Writes max(1, numTriangles - 1) nodes at
   // outNodes[0..] whose inner references are nodeBase-relative absolutes and numTriangles triangle
-  // slots at outTriangles[3 * triangleBase ..]. rootBounds receives the (padded) object-space box.
+  // slots at outTriangles[3 * triangleBase ..] (+ the 144-byte shading records at outShadeTriangles[9 * triangleBase ..]). rootBounds receives the (padded) object-space box.
   hipError_t buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
-                            BvhNode* outNodes, int nodeBase, float4* outTriangles, int triangleBase, float rootBounds[6]);
+                            BvhNode* outNodes, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6]);
 
   // Top level over instance boxes given on the host. Leaf reference = ~instance index.
   hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, int nodeBase);

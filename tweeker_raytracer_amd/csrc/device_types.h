@@ -4,7 +4,7 @@
 // and recurses raygen → trace → closesthit → trace(shadow), this renderer streams fixed-size records
 // between kernels:
 //   ray queue      32 B  (origin.xyz, tmin | direction.xyz, tmax) + 4 B launch index
-//   hit record     16 B  (t, beta, gamma, primitive) + 4 B instance
+//   hit record     16 B  (t, beta, gamma, triangle slot) + 4 B instance
 //   path state     per launch index: throughput+pdf 16 B, radiance 16 B, seed+flags 8 B, volume stack 64 B
 //   shadow queue   ray 32 B + 4 B launch index + pending contribution 16 B
 //   BVH2 node      64 B  (two child boxes + two child references)
@@ -108,6 +108,7 @@ struct LaunchParams
   // scene
   const BvhNode*     nodes;
   const float4*      triangles;      // 3 per triangle slot
+  const float4*      shadeTriangles; // 9 per triangle slot: the three vertices' vertex, tangent, normal, texcoord
   const DevInstance* instances;
   const float*       attributes;     // 12 floats per vertex
   const unsigned int* indices;
@@ -139,7 +140,7 @@ struct LaunchParams
   float4* rayOrg[2];     // origin.xyz, tmin   — two queues, ping-pong per bounce
   float4* rayDir[2];     // direction.xyz, tmax
   unsigned int* rayPixel[2];
-  float4* hitRecord;     // t, beta, gamma, primitive (bits)
+  float4* hitRecord;     // t, beta, gamma, triangle slot (bits)
   int*    hitInstance;
   float4* shadowOrg;
   float4* shadowDir;

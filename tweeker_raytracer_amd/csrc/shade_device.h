@@ -520,22 +520,20 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   {
     // ---- __closesthit__radiance, closesthit.cu:126-305
     const DevInstance& inst = p.instances[instanceIndex];
-    const unsigned int prim = (unsigned int) __float_as_int(hit.w);
-    const unsigned int* tri = p.indices + inst.indexBase + 3 * (size_t) prim;
-    const float* a0 = p.attributes + 12 * (size_t) (inst.attributeBase + tri[0]);
-    const float* a1 = p.attributes + 12 * (size_t) (inst.attributeBase + tri[1]);
-    const float* a2 = p.attributes + 12 * (size_t) (inst.attributeBase + tri[2]);
+    // the three vertices' attributes, gathered per triangle slot at build time (bvh_build.hip emitTrianglesKernel)
+    const float4* sv = p.shadeTriangles + 9 * (size_t) __float_as_int(hit.w);
+    const float4 s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3], s4 = sv[4], s5 = sv[5], s6 = sv[6], s7 = sv[7], s8 = sv[8];
 
     const float beta = hit.y, gamma = hit.z;
     const float alpha = 1.0f - beta - gamma;
 
-    const V3 v0 = v3(a0[0], a0[1], a0[2]), v1 = v3(a1[0], a1[1], a1[2]), v2 = v3(a2[0], a2[1], a2[2]);
+    const V3 v0 = v3(s0.x, s0.y, s0.z), v1 = v3(s3.x, s3.y, s3.z), v2 = v3(s6.x, s6.y, s6.z);
     const V3 ng = cross(v1 - v0, v2 - v0);
-    const V3 tg = v3(a0[3], a0[4], a0[5]) * alpha + v3(a1[3], a1[4], a1[5]) * beta + v3(a2[3], a2[4], a2[5]) * gamma;
-    const V3 ns = v3(a0[6], a0[7], a0[8]) * alpha + v3(a1[6], a1[7], a1[8]) * beta + v3(a2[6], a2[7], a2[8]) * gamma;
+    const V3 tg = v3(s0.w, s1.x, s1.y) * alpha + v3(s3.w, s4.x, s4.y) * beta + v3(s6.w, s7.x, s7.y) * gamma;
+    const V3 ns = v3(s1.z, s1.w, s2.x) * alpha + v3(s4.z, s4.w, s5.x) * beta + v3(s7.z, s7.w, s8.x) * gamma;
 
     SurfaceState state;
-    state.texcoord = v3(a0[9], a0[10], a0[11]) * alpha + v3(a1[9], a1[10], a1[11]) * beta + v3(a2[9], a2[10], a2[11]) * gamma;
+    state.texcoord = v3(s2.y, s2.z, s2.w) * alpha + v3(s5.y, s5.z, s5.w) * beta + v3(s8.y, s8.z, s8.w) * gamma;
 
     state.normalGeo = normalize(transformNormal(inst.worldToObject, ng));
     state.tangent   = normalize(transformVector(inst.objectToWorld, tg));

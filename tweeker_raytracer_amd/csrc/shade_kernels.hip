@@ -96,29 +96,72 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 // ---------------------------------------------------------------------------------------------
 // One thread per ray of queue (depth & 1): shadePath(), then append the continuation ray to queue ((depth + 1) & 1)
 // and the shadow ray (with the pending contribution) to the shadow queue.
-__global__ void __launch_bounds__(256) shadeKernel(LaunchParams p, int depth)
+//
+// Queue appends are aggregated per BLOCK: every wave counts its appenders with a ballot, the block sums the wave
+// counts through LDS and one lane issues ONE returning atomic per queue per block iteration. With one atomic per
+// wave the two counter words saw ~110 k returning atomics per step and the kernel sat in s_waitcnt for 87 % of its
+// wave-cycles (a single word sustains ~90 atomics/us on this chip: MI355X_MICROARCH "dequeue").
+#ifndef TWK_SHADE_WAVES
+#define TWK_SHADE_WAVES 4
+#endif
+#define TWK_SHADE_BLOCK 512
+
+__global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(LaunchParams p, int depth)
 {
+  __shared__ unsigned int waveCount[2][TWK_SHADE_BLOCK / 64];
+  __shared__ unsigned int blockBase[2];
+
   const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const int q = depth & 1, qn = q ^ 1;
   unsigned int* nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + 0];
   unsigned int* shadowCount = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 1];
   unsigned int statHit = 0, statMiss = 0;
 
-  for (unsigned int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numRays; slot += gridDim.x * blockDim.x)
-  {
-    const float4 ro = p.rayOrg[q][slot];
-    const float4 rd = p.rayDir[q][slot];
-    if (rd.w < 0.0f) continue; // inactive launch index (tile column beyond the image)
-    const unsigned int pixel = p.rayPixel[q][slot];
-    const float4 hit = p.hitRecord[slot];
-    const int instanceIndex = p.hitInstance[slot];
+  const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
+  // block-uniform trip count: every thread reaches both barriers of every iteration
+  for (unsigned int base = blockIdx.x * blockDim.x; base < numRays; base += gridDim.x * blockDim.x)
+  {
+    const unsigned int slot = base + threadIdx.x;
     ShadeOutput out;
-    shadePath(p, depth, pixel, ro, rd, hit, instanceIndex, out);
+    out.alive = false; out.wantShadow = false;
+    unsigned int pixel = 0;
+    if (slot < numRays)
+    {
+      const float4 ro = p.rayOrg[q][slot];
+      const float4 rd = p.rayDir[q][slot];
+      if (rd.w >= 0.0f) // else: inactive launch index (tile column beyond the image)
+      {
+        pixel = p.rayPixel[q][slot];
+        const float4 hit = p.hitRecord[slot];
+        const int instanceIndex = p.hitInstance[slot];
+        shadePath(p, depth, pixel, ro, rd, hit, instanceIndex, out);
+        if (p.stats != nullptr) { if (instanceIndex < 0) ++statMiss; else ++statHit; }
+      }
+    }
+
+    const unsigned long long shadowMask = __ballot(out.wantShadow);
+    const unsigned long long nextMask   = __ballot(out.alive);
+    if (lane == 0)
+    {
+      waveCount[0][wave] = (unsigned int) __popcll(shadowMask);
+      waveCount[1][wave] = (unsigned int) __popcll(nextMask);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+    {
+      unsigned int total = 0;
+      for (unsigned int w = 0; w < TWK_SHADE_BLOCK / 64; ++w) total += waveCount[threadIdx.x][w];
+      blockBase[threadIdx.x] = (total != 0u) ? atomicAdd((threadIdx.x == 0) ? shadowCount : nextCount, total) : 0u;
+    }
+    __syncthreads();
+    unsigned int shadowOffset = blockBase[0], nextOffset = blockBase[1];
+    for (unsigned int w = 0; w < wave; ++w) { shadowOffset += waveCount[0][w]; nextOffset += waveCount[1][w]; }
 
     if (out.wantShadow)
     {
-      const unsigned int s = waveAppend(shadowCount);
+      const unsigned int s = shadowOffset + (unsigned int) __popcll(shadowMask & laneBelow);
       p.shadowOrg[s]     = make_float4(out.nextPos.x, out.nextPos.y, out.nextPos.z, p.sceneEpsilon);
       p.shadowDir[s]     = make_float4(out.shadowDir.x, out.shadowDir.y, out.shadowDir.z, out.shadowTmax);
       p.shadowPixel[s]   = pixel;
@@ -126,16 +169,12 @@ __global__ void __launch_bounds__(256) shadeKernel(LaunchParams p, int depth)
     }
     if (out.alive)
     {
-      const unsigned int n = waveAppend(nextCount);
+      const unsigned int n = nextOffset + (unsigned int) __popcll(nextMask & laneBelow);
       p.rayOrg[qn][n]   = make_float4(out.nextPos.x, out.nextPos.y, out.nextPos.z, p.sceneEpsilon);
       p.rayDir[qn][n]   = make_float4(out.nextDir.x, out.nextDir.y, out.nextDir.z, RT_DEFAULT_MAX);
       p.rayPixel[qn][n] = pixel;
     }
-
-    if (p.stats != nullptr)
-    {
-      if (instanceIndex < 0) ++statMiss; else ++statHit;
-    }
+    __syncthreads(); // waveCount / blockBase are rewritten by the next iteration
   }
 
   if (p.stats != nullptr)
@@ -231,7 +270,7 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 }
 void launchShade(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
-  hipLaunchKernelGGL(shadeKernel, dim3(gridBlocks), dim3(256), 0, stream, p, depth);
+  hipLaunchKernelGGL(shadeKernel, dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {

@@ -84,7 +84,7 @@ tailKernel(LaunchParams p, int depth0)
       {
         TraceResult res;
         traverse<COUNT>(p, v3(ro), v3(rd), ro.w, rd.w, false, ldsStack, spill, res, nodeCount, triCount, instCount);
-        hit = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+        hit = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
         inst = res.instance;
         if (COUNT) ++rays;
       }

@@ -109,6 +109,7 @@ struct TraceResult
 {
   float t, beta, gamma;
   int   instance, primitive;
+  int   triangleSlot; // slot of the hit triangle in the leaf-ordered arrays (what shading indexes)
 };
 
 // COUNT: tally node / triangle / instance visits (measurement builds only).
@@ -118,7 +119,7 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
                     unsigned int& nodeCount, unsigned int& triCount, unsigned int& instCount)
 {
   const int stride = TWK_TRACE_BLOCK;
-  res.t = tmax; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1;
+  res.t = tmax; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
 
   TraceRay ray;
   setupRay(ray, org, dir);
@@ -206,7 +207,7 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
                                  (payload < res.instance || (payload == res.instance && prim < res.primitive)));
             if (closer)
             {
-              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim;
+              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim; res.triangleSlot = slot;
               if (anyHit) { stop = true; break; }
             }
           }
@@ -240,7 +241,7 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
                                (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
           if (closer)
           {
-            res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
+            res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim; res.triangleSlot = slot;
             if (anyHit) { stop = true; break; }
           }
         }

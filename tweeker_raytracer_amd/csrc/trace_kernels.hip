@@ -51,27 +51,33 @@ traceKernel(LaunchParams p, int depth)
 
   unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0, maxSteps = 0;
 
-  // Wave-uniform pool of queue slots. The FIRST ticket of every wave is static (wave w owns slots
-  // [w * T, (w + 1) * T)), later ones come from the atomic counter and start behind the static region: an empty
-  // or nearly empty launch (deep bounces) touches no atomic at all — 6144 waves hitting one counter word cost
-  // ~100 us per launch before (measured with an all-miss camera). T adapts to the queue: short queues are spread
-  // over all waves (down to 16 rays per wave) instead of filling a quarter of the chip with 64-ray batches.
+  // Wave-uniform pool of queue slots. Most of the queue is handed out statically: wave w owns the contiguous range
+  // [w * S, (w + 1) * S) with S = 3/4 of its fair share (a multiple of 64), the last quarter is dealt dynamically in
+  // tickets of 64 from one atomic counter for load balance. Short queues (deep bounces) are spread over all waves
+  // in one static ticket of 16..64 rays and touch no atomic at all. Why: 6144 waves hitting one counter word cost
+  // ~100 us per EMPTY launch, and one word sustains only ~90 returning atomics/us (MI355X_MICROARCH "dequeue").
   const unsigned int numWaves = gridDim.x * (TWK_TRACE_BLOCK / 64);
   const unsigned int waveId   = blockIdx.x * (TWK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
-  unsigned int ticketSize = (total + numWaves - 1u) / numWaves;
-  ticketSize = min(64u, max(16u, (ticketSize + 15u) & ~15u));
-  const unsigned int staticEnd = numWaves * ticketSize; // slots handed out without the counter
-  unsigned int poolBase = waveId * ticketSize;
-  unsigned int poolCount = (poolBase < total) ? min(ticketSize, total - poolBase) : 0u;
-  bool exhausted = (poolCount == 0u);
-  if (exhausted) return;
+  unsigned int staticShare = ((total / numWaves) * 3u / 4u) & ~63u;
+  unsigned int ticketSize = 64u;
+  if (staticShare < 64u)
+  {
+    ticketSize = (total + numWaves - 1u) / numWaves;
+    ticketSize = min(64u, max(16u, (ticketSize + 15u) & ~15u));
+    staticShare = ticketSize;
+  }
+  const unsigned int staticEnd = numWaves * staticShare; // slots handed out without the counter
+  unsigned int poolBase = waveId * staticShare;
+  unsigned int poolCount = (poolBase < total) ? min(staticShare, total - poolBase) : 0u;
+  if (poolCount == 0u && staticEnd >= total) return; // nothing for this wave: no ray, no atomic
+  bool exhausted = false;
 
   // per-lane ray state
   bool hasRay = false, anyHit = false, done = false; // done: the lane's ray completed and its result is not yet written
   unsigned int slot = 0;
   V3 org = v3(0.0f), dir = v3(0.0f);
   float tmin = 0.0f;
-  TraceResult res; res.t = 0.0f; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1;
+  TraceResult res; res.t = 0.0f; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
   TraceRay ray; ray.o = v3(0.0f); ray.d = v3(0.0f); ray.id = v3(0.0f);
   WoopConstants woop; woop.kx = 0; woop.ky = 1; woop.kz = 2; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
@@ -109,7 +115,7 @@ traceKernel(LaunchParams p, int depth)
             if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; anyHit = false; }
             else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; anyHit = true; }
             org = v3(o); dir = v3(d); tmin = o.w;
-            res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1;
+            res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
             setupRay(ray, org, dir);
             currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
             hasRay = true;
@@ -204,7 +210,7 @@ traceKernel(LaunchParams p, int depth)
                                        (payload < res.instance || (payload == res.instance && prim < res.primitive)));
                   if (closer)
                   {
-                    res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim;
+                    res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim; res.triangleSlot = ts;
                     if (anyHit) { pop = false; hasRay = false; done = true; break; }
                   }
                 }
@@ -240,7 +246,7 @@ traceKernel(LaunchParams p, int depth)
                                      (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
                 if (closer)
                 {
-                  res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim;
+                  res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim; res.triangleSlot = ts;
                   if (anyHit) { pop = false; hasRay = false; done = true; break; }
                 }
               }
@@ -271,7 +277,7 @@ traceKernel(LaunchParams p, int depth)
         if (continue_after_overflow) { continue_after_overflow = false; }
         else if (!anyHit)
         {
-          p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+          p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
           p.hitInstance[slot] = res.instance;
           if (COUNT) ++closestCount;
           if (p.firstHit != nullptr && depth == 0)
@@ -338,7 +344,7 @@ traceOverflowKernel(LaunchParams p, int depth)
       const float4 o = p.rayOrg[q][slot];
       const float4 d = p.rayDir[q][slot];
       traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, false, ldsStack, spill, res, nodeCount, triCount, instCount);
-      p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+      p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
       p.hitInstance[slot] = res.instance;
       if (p.firstHit != nullptr && depth == 0)
       {
