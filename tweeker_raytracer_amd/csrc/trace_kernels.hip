@@ -28,6 +28,9 @@ namespace twk {
 //   * "while-while": all lanes first descend inner nodes together, then handle their leaf / instance entry /
 //     instance exit once, so a wave does not pay for three code paths per step.
 #define TWK_TRACE_REFILL 44
+#ifndef TWK_TRACE_NODE_FRACTION
+#define TWK_TRACE_NODE_FRACTION 4
+#endif
 
 template<bool COUNT>
 #ifndef TWK_TRACE_WAVES
@@ -133,6 +136,7 @@ traceKernel(LaunchParams p, int depth)
     // ---- traverse until enough lanes have finished to be worth a refill ------------------------------
     for (;;)
     {
+      const int roundActive = __popcll(__ballot(hasRay));
       // All lanes descend inner nodes. Kept flat on purpose: the stack lives in LDS only here, push and pop are
       // straight-line predicated code (nested LDS/HBM stack selects compiled to ~70 scalar branch instructions
       // per node). A lane whose stack would overflow abandons this traversal and re-traces its ray with the
@@ -163,10 +167,14 @@ traceKernel(LaunchParams p, int depth)
           node = ldsStack[sp * stride];
         }
         if (stop || retrace) { hasRay = false; done = true; }
+        // Leave the node loop once most lanes are parked at a leaf: the stragglers resume in the next round
+        // together with the lanes that come back from their leaf, instead of running at a few lanes per wave.
+        if (__popcll(__ballot(hasRay && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_FRACTION < roundActive) break;
       }
 
-      // one leaf / instance-entry / instance-exit step per lane
-      if (hasRay)
+      // one leaf / instance-entry / instance-exit step per lane; lanes that left the node loop early are still
+      // at an inner node and must NOT take this path (their `node` is not a leaf reference)
+      if (hasRay && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
       {
         bool pop = false;
         if (node == TWK_BVH_SENTINEL)
