@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of the traversal kernel from rocprofv3 --pmc passes (tools/pmc_collect.sh):
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of 16-B-per-lane reads
+(MI355X_MICROARCH.md §HBM), so it is doubled; WRITE_SIZE is exact for 16-B stores. Averages per dispatch of
+twk::traceKernel<false>. usage: tools/pmc_traffic.py gpurun_out/<tag> profiles/r01_trace_hbm_traffic.json"""
+import csv, glob, json, os, sys
+
+root, out = sys.argv[1], sys.argv[2]
+acc = {}
+for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(path)):
+        if "traceKernel<false>" not in r["Kernel_Name"]:
+            continue
+        c = r["Counter_Name"]
+        if c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"):
+            a = acc.setdefault(c, [0.0, set()])
+            a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
+per = {c: v[0] / max(1, len(v[1])) for c, v in acc.items()}
+res = {
+    "kernel": "twk::traceKernel<false>",
+    "dispatches": len(acc["FETCH_SIZE"][1]),
+    "fetch_size_kib_per_launch": per["FETCH_SIZE"],
+    "write_size_kib_per_launch": per["WRITE_SIZE"],
+    "fetch_correction": 2.0,
+    "hbm_bytes_per_launch": (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0,
+    "l2_hit_rate": per.get("TCC_HIT_sum", 0) / max(1.0, per.get("TCC_HIT_sum", 0) + per.get("TCC_MISS_sum", 0)),
+    "note": "launches of 8 iterations (default batch); separate --pmc passes for FETCH_SIZE and WRITE_SIZE; counters include Infinity-Cache hits (memory-side of L2)",
+}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res))
