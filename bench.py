@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N > 1 path on ONE GPU: all ranks share device 0, the gather goes over gloo through host memory")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,10 +71,15 @@ def main():
     import tweeker_raytracer_amd as twk
 
     dist = None
+    if args.rehearse_gloo:
+        local_rank = 0
     if n_gpus > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     device = torch.device("cuda", local_rank)
     width, height = frame_for(n_gpus)
@@ -98,13 +105,30 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def check_composite():
+        """N > 1 only, after the timed region: the composed image must equal a single-device render of the frame."""
+        single = twk.Device(ordinal=local_rank, miss=info.miss)
+        app.initDevice(single)
+        for it in range(0, args.warmup + args.steps):  # the accumulator keeps the warm-up iterations, like the ranks' buffers
+            single.render(it)
+        ref_img = single.getOutputBufferHost()
+        single.close()
+        return bool(np.array_equal(ref_img.view(np.uint32), composed.cpu().numpy().view(np.uint32)))
+
     def run_steps(first, count, finish=True):
         for it in range(first, first + count):
             dev.render(it)
         dev.synchronizeStream()
         if dist is not None and finish:
             # the one exchange step of the path: gather the packed tile buffers, scatter into the image
-            dist.gather(accum, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if args.rehearse_gloo:
+                host = accum.cpu()
+                parts = [torch.empty_like(host) for _ in range(n_gpus)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    gathered.copy_(torch.stack(parts))
+            else:
+                dist.gather(accum, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
             if rank == 0:
                 torch.cuda.synchronize(device)
                 dev.compositor(gathered.data_ptr(), composed.data_ptr())
@@ -120,6 +144,10 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    composite_ok = None
+    if dist is not None and rank == 0 and os.environ.get("TWK_BENCH_CHECK_COMPOSITE", "1" if args.rehearse_gloo else "0") == "1":
+        composite_ok = check_composite()
 
     samples = float(width) * float(height) * float(args.steps)
     result = {
@@ -143,6 +171,10 @@ def main():
             "parallelism": "single GPU" if n_gpus == 1 else f"tile-interleaved pixels over {n_gpus} ranks (8x8 tiles), one RCCL gather + compositor at the end",
         },
     }
+    if composite_ok is not None:
+        result["config"]["composite_bit_identical_to_single_device"] = composite_ok
+    if args.rehearse_gloo:
+        result["config"]["rehearsal"] = "gloo, all ranks on GPU 0 — NOT a scaling measurement"
 
     # ---- roofline of the dominant kernel (traversal), measured on the same steps --------------------
     if not args.no_roofline and rank == 0:
