@@ -56,18 +56,28 @@ static inline float3 interpolateTexcoord(const HitContext& hc)
 }
 
 // anyhit.cu:46-80 (radiance) and :94-132 (shadow): returns true when the candidate hit is ignored.
-static inline bool cutoutIgnores(const Oracle& o, const HitContext& hc, PerRayData* prd)
+static inline bool cutoutIgnores(const Oracle& o, const HitContext& hc, unsigned int& seed)
 {
   MaterialDefinition const& material = o.sys.materialDefinitions[hc.inst->material];
   if (material.textureCutout == 0) return false;
   const float3 texcoord = interpolateTexcoord(hc);
   const float opacity = intensity(make_float3(tex2D(o.sys.textures[1], texcoord.x, texcoord.y)));
-  return (opacity < 1.0f && opacity <= rng(prd->seed));
+  return (opacity < 1.0f && opacity <= rng(seed));
 }
 
-// optixTrace: closest hit with the cutout any-hit filter applied to candidates.
-// Cutout any-hit draws rng per candidate in traversal order (anyhit.cu:75) which is implementation
-// defined in OptiX; here candidates are visited closest-first by re-tracing past ignored hits.
+// Cutout opacity — what is pinned and what is a choice of this build (SURVEY.md §7 "RNG-stream fidelity"):
+// OptiX invokes the any-hit program once per candidate intersection in TRAVERSAL order, which is implementation
+// defined inside libnvoptix, and every invocation draws from the path's LCG (anyhit.cu:75,122). Here candidates are
+// visited closest-first (re-trace strictly behind an ignored candidate), each exactly once:
+//   * radiance rays draw from the path's seed, before the closest-hit program runs — as in the reference;
+//   * shadow rays draw from a stream FORKED from the path's seed when the shadow ray is emitted
+//     (tea<2>(seed, 'SHDW')), so that the visibility test does not feed back into the path's later draws. The
+//     reference couples them (the Russian-roulette draw follows the shadow ray's any-hit draws); decoupling keeps
+//     the shadow ray of bounce k independent of the path's continuation, which the wavefront schedule relies on.
+//     Statistically equivalent, not sample-identical to an OptiX run (which is not reproducible across OptiX
+//     versions either).
+static const unsigned int SHADOW_FORK = 0x53484457u; // 'SHDW'
+
 static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const float3& dir, float tmin, float tmax)
 {
   o.radianceRays++;
@@ -78,7 +88,7 @@ static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const fl
     if (h.instance < 0) return h;
     const Instance& inst = o.scene.instances[h.instance];
     HitContext hc = { &inst, &o.scene.geometries[inst.geometry], h.primitive, h.beta, h.gamma, h.t };
-    if (!cutoutIgnores(o, hc, prd)) return h;
+    if (!cutoutIgnores(o, hc, prd->seed)) return h;
     lo = h.t; // continue strictly behind the ignored candidate
   }
 }
@@ -87,12 +97,13 @@ static bool traceShadow(Oracle& o, PerRayData* prd, const float3& org, const flo
 {
   o.shadowRays++;
   bool anyCutout = false;
-  for (const Instance& inst : o.scene.instances)
-    if (o.sys.materialDefinitions[inst.material].textureCutout != 0) { anyCutout = true; break; }
+  for (const MaterialDefinition& m : o.sys.materialDefinitions)
+    if (m.textureCutout != 0) { anyCutout = true; break; }
   if (!anyCutout)
   {
     return o.scene.trace(org, dir, tmin, tmax, true).instance >= 0; // anyhit.cu:84-91
   }
+  unsigned int shadowSeed = tea<2>(prd->seed, SHADOW_FORK);
   float lo = tmin;
   for (;;)
   {
@@ -100,7 +111,7 @@ static bool traceShadow(Oracle& o, PerRayData* prd, const float3& org, const flo
     if (h.instance < 0) return false;
     const Instance& inst = o.scene.instances[h.instance];
     HitContext hc = { &inst, &o.scene.geometries[inst.geometry], h.primitive, h.beta, h.gamma, h.t };
-    if (!cutoutIgnores(o, hc, prd)) return true; // anyhit.cu:127-131
+    if (!cutoutIgnores(o, hc, shadowSeed)) return true; // anyhit.cu:127-131
     lo = h.t;
   }
 }

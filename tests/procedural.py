@@ -31,3 +31,15 @@ def albedo_checker(size=64):
     out = np.ones((size, size, 4), np.float32)
     out[..., :3] = colours[idx]
     return out
+
+
+def cutout_slots(size=64):
+    """Slot pattern for cutout opacity: opaque bars (1), half-transparent bars (0.5, exercises the stochastic draw)
+    and holes (0) — the role of slots_alpha.png, which the reference repository does not contain."""
+    y, x = np.mgrid[0:size, 0:size]
+    band = (x // 4) % 4
+    op = np.where(band == 0, 0.0, np.where(band == 1, 0.5, 1.0)).astype(np.float32)
+    op = np.where((y // 16) % 2 == 0, op, 1.0).astype(np.float32)
+    out = np.ones((size, size, 4), np.float32)
+    out[..., 0] = out[..., 1] = out[..., 2] = op
+    return out

@@ -1,8 +1,9 @@
 """-m gpu: parity of the remaining reference programs and configurations against the oracle, all bit-identical:
   C4   geometry scene (constant environment miss 1 + env light sampling, GGX BRDF, rough-glass BSDF, torus, box,
        open half sphere) and the instanced scene (101 instances of 5 geometries, two-level BVH)
-  C3-  spherical HDR environment (miss 2: importance sampling through the CDFs of Texture::calculateSphericalCDF,
-       miss_env_sphere MIS) + albedo texture (tex2D bilinear)      [cutout opacity is not implemented: DESIGN.md §9]
+  C3   intro_07 scene: spherical HDR environment (miss 2: importance sampling through the CDFs of
+       Texture::calculateSphericalCDF, miss_env_sphere MIS), albedo texture (tex2D bilinear), nested dielectrics,
+       stochastic cutout opacity on radiance and shadow rays
   lens fisheye and sphere lens shaders
   C5   the 3840x2160 frame tiled over 8 device indices (launchWidth 480): crop parity of one tile set
   compositor kernel
@@ -11,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import load_app, scene_path
-from procedural import albedo_checker, environment_hdr
+from procedural import albedo_checker, cutout_slots, environment_hdr
 
 pytestmark = pytest.mark.gpu
 
@@ -115,14 +116,60 @@ def test_lens_shaders(twk, orc, lens):
     dev.close()
 
 
-def test_cutout_is_rejected_loudly(twk):
-    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (32, 32))
+def _intro07(twk, res):
+    app = load_app(twk, "system_intro_07.txt", "scene_intro_07.txt", res)
+    names = {"floor": 1, "cutout": 4}  # material 0 is the area light's (Application.cpp:640-659), then file order
+
+    def edit(mats):
+        assert mats[names["floor"]].indexBSDF == 0 and mats[names["cutout"]].thinwalled == 1
+        mats[names["floor"]].useAlbedoTexture = 1
+        mats[names["cutout"]].useCutoutTexture = 1
+
+    textures = ((0, albedo_checker()), (1, cutout_slots()), (2, environment_hdr()))
+    return app, edit, textures
+
+
+def test_c3_intro07_with_cutout_opacity(twk, orc):
+    """Config C3: intro_07 scene — albedo texture, spherical HDR environment + 4x4 area light (two lights: the light
+    pick draws rng), nested dielectrics (glass sphere inside the water box), mirror torus and a sphere with stochastic
+    cutout opacity on radiance AND shadow rays. Bit-identical to the oracle (which defines the candidate order)."""
+    app, edit, textures = _intro07(twk, (160, 90))
+    assert app.info.numLights == 2 and app.info.numInstances == 6
+    dev, ref = _both(twk, orc, app, 3, textures=textures, material_edit=edit)
+    gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+    assert np.isfinite(cpu).all() and cpu[..., :3].max() > 1.0
+    mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+    assert mism == 0, f"{mism} pixels differ, max |diff| {np.abs(gpu - cpu).max()}"
+    # the cutout really cuts: with the texture off the image differs
+    dev2, _ = _both(twk, orc, app, 0, textures=textures)
+    for it in range(3):
+        dev2.render(it)
+    assert not np.array_equal(_bits(dev2.getOutputBufferHost()), _bits(gpu))
+    dev.close()
+    dev2.close()
+
+
+def test_c3_full_size_crop(twk, orc):
+    """C3 at its full 1920x1080: crop parity of a window that straddles the cutout sphere."""
+    app, edit, textures = _intro07(twk, None)
+    x0, y0, x1, y1 = 930, 500, 994, 540
+    dev, ref = _both(twk, orc, app, 2, textures=textures, material_edit=edit, rect=(x0, y0, x1, y1))
+    gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+    assert np.array_equal(_bits(gpu[y0:y1, x0:x1]), _bits(cpu[y0:y1, x0:x1]))
+    dev.close()
+
+
+def test_missing_texture_is_an_error(twk):
+    app, edit, textures = _intro07(twk, (32, 18))
     dev = twk.Device(ordinal=0, miss=app.info.miss)
+    dev.initTexture(2, environment_hdr())
+    app.initDevice(dev)
     mats = app.materials
-    mats[1].useCutoutTexture = 1
+    edit(mats)
+    dev.initMaterials(mats)
     with pytest.raises(twk.TwkError) as e:
-        dev.initMaterials(mats)
-    assert "cutout" in str(e.value)
+        dev.render(0)
+    assert "texture" in str(e.value)
     dev.close()
 
 

@@ -197,6 +197,8 @@ static void refreshParams(TwkDevice dev)
   p.numInstances = (int) dev->instances.size();
   p.numLights = (int) dev->lights.size();
   p.miss = dev->miss;
+  p.hasCutout = 0;
+  for (const DevMaterial& m : dev->materials) if (m.textureCutout != 0) p.hasCutout = 1;
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)
   {
@@ -572,7 +574,6 @@ int twk_init_materials(TwkDevice dev, const TwkMaterialGUI* m, int count)
   for (int i = 0; i < count; ++i)
   {
     if (m[i].indexBSDF < 0 || m[i].indexBSDF > 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: indexBSDF out of range");
-    if (m[i].useCutoutTexture) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: cutout opacity (stochastic any-hit, anyhit.cu:46-132) is not implemented in this build");
   }
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->materials.resize(count);
@@ -591,7 +592,7 @@ int twk_update_material(TwkDevice dev, int idMaterial, const TwkMaterialGUI* m)
 {
   int rc = activate(dev, "twk_update_material"); if (rc) return rc;
   if (!m || idMaterial < 0 || idMaterial >= (int) dev->materials.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_material: bad material id");
-  if (m->indexBSDF < 0 || m->indexBSDF > 4 || m->useCutoutTexture) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_material: unsupported material");
+  if (m->indexBSDF < 0 || m->indexBSDF > 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_material: indexBSDF out of range");
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->materials[idMaterial] = convertMaterial(*m);
   HIP_TRY(hipMemcpyAsync(dev->d_materials + idMaterial, &dev->materials[idMaterial], sizeof(DevMaterial), hipMemcpyHostToDevice, dev->stream));
@@ -758,7 +759,11 @@ int twk_launch(TwkDevice dev, unsigned int iterationIndex)
   if (dev->cameras.empty() || dev->materials.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: cameras and materials are required");
   if (dev->miss == 2 && dev->d_texels[TWK_TEXTURE_ENVIRONMENT] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: miss 2 needs an environment texture");
   for (const DevMaterial& m : dev->materials)
+  {
     if (m.textureAlbedo && dev->d_texels[TWK_TEXTURE_ALBEDO] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: a material uses the albedo texture but none was uploaded");
+    if (m.textureCutout && dev->d_texels[TWK_TEXTURE_CUTOUT] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: a material uses the cutout texture but none was uploaded");
+    if (m.textureCutout && dev->tailDepth > 0) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: the tail kernel (TWK_TAIL_DEPTH) does not implement cutout opacity");
+  }
 
   // Asynchronous like optixLaunch: the iteration is recorded; consecutive iterations are rendered together (up to
   // batchMax samples per pixel per wavefront pass). Results are identical to one pass per iteration.

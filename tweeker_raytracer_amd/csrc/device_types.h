@@ -122,6 +122,7 @@ struct LaunchParams
   int   numInstances;
   int   numLights;
   int   miss;
+  int   hasCutout;      // some material has cutout opacity: trace kernels run the stochastic any-hit candidate loop
   unsigned int envWidth, envHeight;
   float envIntegral, envRotation;
 

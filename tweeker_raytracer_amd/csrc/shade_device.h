@@ -450,6 +450,7 @@ struct ShadeOutput
   V3    shadowDir;
   float shadowTmax;
   V3    pending;     // throughput * MIS-weighted next-event contribution
+  unsigned int shadowSeed; // cutout scenes: RNG stream of the shadow ray's any-hit draws, forked from the path's seed
 };
 
 TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const float4& ro, const float4& rd,
@@ -630,6 +631,7 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   out.wantShadow = wantShadow;
   out.shadowDir = shadowDir; out.shadowTmax = shadowTmax;
   out.pending = throughput * contribution;
+  out.shadowSeed = (wantShadow && p.hasCutout) ? tea<2>(prd.seed, 0x53484457u /* 'SHDW' */) : 0u;
   if (!wantShadow)
   {
     // emission / environment (or nothing): radiance += throughput * prd.radiance

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(
       p.shadowOrg[s]     = make_float4(out.nextPos.x, out.nextPos.y, out.nextPos.z, p.sceneEpsilon);
       p.shadowDir[s]     = make_float4(out.shadowDir.x, out.shadowDir.y, out.shadowDir.z, out.shadowTmax);
       p.shadowPixel[s]   = pixel;
-      p.shadowPending[s] = make_float4(out.pending.x, out.pending.y, out.pending.z, 0.0f);
+      p.shadowPending[s] = make_float4(out.pending.x, out.pending.y, out.pending.z, __uint_as_float(out.shadowSeed));
     }
     if (out.alive)
     {

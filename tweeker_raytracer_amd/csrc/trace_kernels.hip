@@ -13,8 +13,46 @@
 // double fallback on zero edge functions, no fused multiply-add. Ties in t go to the smaller
 // (instance, primitive) pair, so the result does not depend on traversal order.
 #include "trace_device.h"
+#include "shade_device.h" // tex2D, rng, tea for the cutout-opacity test
 
 namespace twk {
+
+// Cutout opacity (anyhit.cu:46-80 radiance, :94-132 shadow): stochastic alpha test of ONE candidate hit. Candidates
+// are visited closest-first; radiance rays draw from the path's seed, shadow rays from the stream forked when the ray
+// was emitted (shadowPending.w, see shadePath). Returns true when the candidate is ignored; the caller then restarts
+// the traversal strictly behind it. The new tmin is written back to the ray record so that a re-trace by
+// traceOverflowKernel continues behind the same candidate.
+TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res, bool isShadow, int q, unsigned int slot, unsigned int numClosest)
+{
+  const DevInstance& inst = p.instances[res.instance];
+  const DevMaterial& material = p.materials[inst.material];
+  if (material.textureCutout == 0) return false;
+  const float4* sv = p.shadeTriangles + 9 * (size_t) res.triangleSlot;
+  const float4 s2 = sv[2], s5 = sv[5], s8 = sv[8];
+  const float alpha = 1.0f - res.beta - res.gamma;
+  const V3 texcoord = v3(s2.y, s2.z, s2.w) * alpha + v3(s5.y, s5.z, s5.w) * res.beta + v3(s8.y, s8.z, s8.w) * res.gamma;
+  const float opacity = intensity(v3(tex2D(p.textures[1], texcoord.x, texcoord.y)));
+  if (!(opacity < 1.0f)) return false;
+  float draw;
+  if (isShadow)
+  {
+    float4 pend = p.shadowPending[slot - numClosest];
+    unsigned int seed = __float_as_uint(pend.w);
+    draw = rng(seed);
+    pend.w = __uint_as_float(seed);
+    p.shadowPending[slot - numClosest] = pend;
+  }
+  else
+  {
+    const unsigned int pixel = p.rayPixel[q][slot];
+    uint2 sf = p.pathSeedFlags[pixel];
+    draw = rng(sf.x);
+    p.pathSeedFlags[pixel] = sf;
+  }
+  if (!(opacity <= draw)) return false;
+  if (isShadow) p.shadowOrg[slot - numClosest].w = res.t; else p.rayOrg[q][slot].w = res.t;
+  return true;
+}
 
 // Persistent traversal launch for bounce `depth`: slots [0, numClosest) are the radiance rays of queue
 // (depth & 1), slots [numClosest, numClosest + numShadow) the shadow rays emitted by shade(depth - 1).
@@ -32,7 +70,7 @@ namespace twk {
 #define TWK_TRACE_NODE_FRACTION 4
 #endif
 
-template<bool COUNT>
+template<bool COUNT, bool CUTOUT>
 #ifndef TWK_TRACE_WAVES
 #define TWK_TRACE_WAVES 6
 #endif
@@ -77,6 +115,7 @@ traceKernel(LaunchParams p, int depth)
 
   // per-lane ray state
   bool hasRay = false, anyHit = false, done = false; // done: the lane's ray completed and its result is not yet written
+  bool isShadow = false; // anyHit == isShadow unless the scene has cutout materials (then shadow rays search the closest candidate)
   unsigned int slot = 0;
   V3 org = v3(0.0f), dir = v3(0.0f);
   float tmin = 0.0f;
@@ -115,8 +154,9 @@ traceKernel(LaunchParams p, int depth)
           {
             slot = poolBase + rank;
             float4 o, d;
-            if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; anyHit = false; }
-            else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; anyHit = true; }
+            if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; isShadow = false; }
+            else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; isShadow = true; }
+            anyHit = isShadow && !CUTOUT;
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
             setupRay(ray, org, dir);
@@ -282,8 +322,20 @@ traceKernel(LaunchParams p, int depth)
           continue_after_overflow = true;
         }
         if (COUNT) maxSteps = max(maxSteps, guard);
-        if (continue_after_overflow) { continue_after_overflow = false; }
-        else if (!anyHit)
+        const bool ignoredCandidate = CUTOUT && !continue_after_overflow && res.instance >= 0 &&
+                                      cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest);
+        if (ignoredCandidate)
+        {
+          // continue strictly behind the ignored candidate: restart the traversal with tmin = its distance
+          tmin = res.t;
+          res.t = isShadow ? p.shadowDir[slot - numClosest].w : p.rayDir[q][slot].w;
+          res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
+          setupRay(ray, org, dir);
+          currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
+          hasRay = true;
+        }
+        else if (continue_after_overflow) { continue_after_overflow = false; }
+        else if (!isShadow)
         {
           p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
           p.hitInstance[slot] = res.instance;
@@ -331,7 +383,7 @@ traceKernel(LaunchParams p, int depth)
 // Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again
 // with the single-ray traversal whose stack continues in HBM. Launched behind every traceKernel; exits at once when
 // the list is empty.
-template<bool COUNT>
+template<bool COUNT, bool CUTOUT>
 __global__ void __launch_bounds__(TWK_TRACE_BLOCK)
 traceOverflowKernel(LaunchParams p, int depth)
 {
@@ -346,12 +398,19 @@ traceOverflowKernel(LaunchParams p, int depth)
   for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
   {
     const unsigned int slot = p.overflowSlots[k];
+    const bool isShadow = !(slot < numClosest);
+    const float4 o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
+    const float4 d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+    float tmin = o.w; // carries the distance of the last ignored cutout candidate, if any
     TraceResult res;
-    if (slot < numClosest)
+    for (;;)
     {
-      const float4 o = p.rayOrg[q][slot];
-      const float4 d = p.rayDir[q][slot];
-      traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, false, ldsStack, spill, res, nodeCount, triCount, instCount);
+      traverse<COUNT>(p, v3(o), v3(d), tmin, d.w, isShadow && !CUTOUT, ldsStack, spill, res, nodeCount, triCount, instCount);
+      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest))) break;
+      tmin = res.t;
+    }
+    if (!isShadow)
+    {
       p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
       p.hitInstance[slot] = res.instance;
       if (p.firstHit != nullptr && depth == 0)
@@ -361,20 +420,14 @@ traceOverflowKernel(LaunchParams p, int depth)
         p.firstHitInstance[pixel] = res.instance;
       }
     }
-    else
+    else if (res.instance < 0)
     {
       const unsigned int sIdx = slot - numClosest;
-      const float4 o = p.shadowOrg[sIdx];
-      const float4 d = p.shadowDir[sIdx];
-      traverse<COUNT>(p, v3(o), v3(d), o.w, d.w, true, ldsStack, spill, res, nodeCount, triCount, instCount);
-      if (res.instance < 0)
-      {
-        const unsigned int pixel = p.shadowPixel[sIdx];
-        const float4 c = p.shadowPending[sIdx];
-        float4 r = p.pathRadiance[pixel];
-        r.x += c.x; r.y += c.y; r.z += c.z;
-        p.pathRadiance[pixel] = r;
-      }
+      const unsigned int pixel = p.shadowPixel[sIdx];
+      const float4 c = p.shadowPending[sIdx];
+      float4 r = p.pathRadiance[pixel];
+      r.x += c.x; r.y += c.y; r.z += c.z;
+      p.pathRadiance[pixel] = r;
     }
   }
   if (COUNT)
@@ -415,11 +468,13 @@ traceQueryKernel(LaunchParams p, const float* __restrict__ rays, unsigned int nu
 
 void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream)
 {
-  if (count) hipLaunchKernelGGL(traceKernel<true>,  dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
-  else       hipLaunchKernelGGL(traceKernel<false>, dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
   const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
-  if (count) hipLaunchKernelGGL(traceOverflowKernel<true>,  dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
-  else       hipLaunchKernelGGL(traceOverflowKernel<false>, dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  const dim3 grid(gridBlocks), ogrid(overflowBlocks), block(TWK_TRACE_BLOCK);
+  const bool cutout = (p.hasCutout != 0);
+  if (count && cutout)       { hipLaunchKernelGGL((traceKernel<true, true>),   grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<true, true>),   ogrid, block, 0, stream, p, depth); }
+  else if (count)            { hipLaunchKernelGGL((traceKernel<true, false>),  grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<true, false>),  ogrid, block, 0, stream, p, depth); }
+  else if (cutout)           { hipLaunchKernelGGL((traceKernel<false, true>),  grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<false, true>),  ogrid, block, 0, stream, p, depth); }
+  else                       { hipLaunchKernelGGL((traceKernel<false, false>), grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<false, false>), ogrid, block, 0, stream, p, depth); }
 }
 
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream)
