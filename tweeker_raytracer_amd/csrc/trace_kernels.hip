@@ -65,7 +65,9 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 //     slowest lane (measured: 10.5 of 64 lanes active per VALU instruction);
 //   * "while-while": all lanes first descend inner nodes together, then handle their leaf / instance entry /
 //     instance exit once, so a wave does not pay for three code paths per step.
+#ifndef TWK_TRACE_REFILL
 #define TWK_TRACE_REFILL 44
+#endif
 #ifndef TWK_TRACE_NODE_FRACTION
 #define TWK_TRACE_NODE_FRACTION 4
 #endif
