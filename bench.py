@@ -29,7 +29,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 
 # Algorithmic bytes of the traversal kernel (DESIGN.md "Roofline model"): fixed record sizes, cache hits do not reduce them.
 B_RAY_FIXED = 48      # 32 B ray record in + 16 B hit record out (shadow rays: 32 B ray + 16 B pending contribution)
-B_NODE = 64           # one BVH2 node (both child boxes + references)
+B_NODE = 128          # one 4-ary wide node (four child boxes + references, two 64-byte halves)
 B_TRIANGLE = 48       # one triangle slot (three float4)
 B_INSTANCE = 64       # world-to-object rows + BVH root of the instance record
 

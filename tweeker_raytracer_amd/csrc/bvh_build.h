@@ -9,21 +9,22 @@ class BvhBuilder
 public:
   ~BvhBuilder() { release(); }
 
+  // outWide receives, per inner node, the 128-byte wide node (two BvhNode halves) at outWide[2 * localIndex].
   // Bottom level over the triangles of one geometry. Writes max(1, numTriangles - 1) nodes at
   // outNodes[0..] whose inner references are nodeBase-relative absolutes and numTriangles triangle
   // slots at outTriangles[3 * triangleBase ..] (+ the 144-byte shading records at outShadeTriangles[9 * triangleBase ..]). rootBounds receives the (padded) object-space box.
   hipError_t buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
-                            BvhNode* outNodes, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6]);
+                            BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6]);
 
   // Top level over instance boxes given on the host. Leaf reference = ~instance index.
-  hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, int nodeBase);
+  hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase);
 
   void release();
   void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 8) ? 8 : n); }
 
 private:
   hipError_t reserve(int count);
-  hipError_t buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, int nodeBase, int leafMode, int leafBase);
+  hipError_t buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase);
 
   int m_capacity = 0;
   float4* m_primLo = nullptr; float4* m_primHi = nullptr;

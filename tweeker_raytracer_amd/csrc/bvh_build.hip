@@ -164,6 +164,37 @@ TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const 
   p[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
 }
 
+// Wide (4-ary) node of inner node i = the children of its children, stored as TWO 64-byte halves in the BVH2 node
+// format (two boxes + two references each): a traversal step over a wide node crosses two levels of the binary tree
+// with one round of loads instead of two dependent ones. A child that is a leaf occupies one entry; unused entries
+// get an empty box. Wide nodes share the index space of the binary nodes (every inner node has one; only those at
+// even depth below the root are ever visited).
+struct WideEntry { float4 lo, hi; int ref; };
+
+TWK_D void emptyEntry(WideEntry& e)
+{
+  const float inf = __uint_as_float(0x7f800000u);
+  // lo = hi = +inf: every plane distance is +inf or -inf on both sides, so the slab interval is empty for any ray.
+  // (An inverted box lo > hi does NOT work: the slab test orders the two plane distances itself.)
+  e.lo = make_float4(inf, inf, inf, 0.0f); e.hi = make_float4(inf, inf, inf, 0.0f); e.ref = ~0;
+}
+
+// Expands child `ref` (box lo/hi) into one entry (leaf) or the two entries of its own children (inner node).
+TWK_D void expandChild(const BvhNode* outNodes, int nodeBase, int ref, const float4& lo, const float4& hi, WideEntry* e, int& n)
+{
+  if (ref < 0) { e[n].lo = lo; e[n].hi = hi; e[n].ref = ref; ++n; return; }
+  const float4* c = reinterpret_cast<const float4*>(outNodes + (ref - nodeBase));
+  const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+  e[n].lo = make_float4(c0.x, c0.y, c0.z, 0.0f); e[n].hi = make_float4(c0.w, c1.x, c1.y, 0.0f); e[n].ref = __float_as_int(c3.x); ++n;
+  e[n].lo = make_float4(c1.z, c1.w, c2.x, 0.0f); e[n].hi = make_float4(c2.y, c2.z, c2.w, 0.0f); e[n].ref = __float_as_int(c3.y); ++n;
+}
+
+TWK_D void writeWideNode(BvhNode* wide, const WideEntry* e)
+{
+  writeNode(&wide[0], e[0].lo, e[0].hi, e[1].lo, e[1].hi, e[0].ref, e[1].ref);
+  writeNode(&wide[1], e[2].lo, e[2].hi, e[3].lo, e[3].hi, e[2].ref, e[3].ref);
+}
+
 // One thread per leaf walks up; the second thread to arrive at an inner node (ticket == 1) owns it.
 // leafMode 0 (triangles): leaf reference = ~(first slot | (count - 1) << 28) with first = leafBase + sorted
 // position; a child subtree that covers at most maxLeaf sorted positions is referenced as ONE leaf (its slots are
@@ -175,7 +206,7 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
                             const int* __restrict__ innerParent, const int* __restrict__ leafParent,
                             const int2* __restrict__ range,
                             unsigned int* __restrict__ tickets, float4* nodeLo, float4* nodeHi,
-                            BvhNode* __restrict__ outNodes, int nodeBase, int leafMode, int leafBase, int maxLeaf)
+                            BvhNode* outNodes, BvhNode* __restrict__ outWide, int nodeBase, int leafMode, int leafBase, int maxLeaf)
 {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= count) return;
@@ -216,6 +247,14 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
       c1 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28)) : nodeBase + r;
     }
     writeNode(&outNodes[node], lo0, hi0, lo1, hi1, c0, c1);
+    {
+      WideEntry e[4];
+      int n = 0;
+      expandChild(outNodes, nodeBase, c0, lo0, hi0, e, n);
+      expandChild(outNodes, nodeBase, c1, lo1, hi1, e, n);
+      for (; n < 4; ++n) emptyEntry(e[n]);
+      writeWideNode(&outWide[2 * node], e);
+    }
     nodeLo[node] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
     nodeHi[node] = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
     node = innerParent[node];
@@ -224,13 +263,15 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
 
 // A single primitive has no inner node: emit one node whose second child can never be hit.
 __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi,
-                                 BvhNode* outNodes, float4* nodeLo, float4* nodeHi, int leafMode, int leafBase)
+                                 BvhNode* outNodes, BvhNode* outWide, float4* nodeLo, float4* nodeHi, int leafMode, int leafBase)
 {
   float4 lo = primLo[0], hi = primHi[0];
   padBox(lo, hi);
   const float inf = __uint_as_float(0x7f800000u);
-  const float4 elo = make_float4(inf, inf, inf, 0.0f), ehi = make_float4(-inf, -inf, -inf, 0.0f);
+  const float4 elo = make_float4(inf, inf, inf, 0.0f), ehi = make_float4(inf, inf, inf, 0.0f); // never hit, see emptyEntry()
   writeNode(&outNodes[0], lo, hi, elo, ehi, (leafMode == 0) ? ~leafBase : ~0, ~0);
+  writeNode(&outWide[0], lo, hi, elo, ehi, (leafMode == 0) ? ~leafBase : ~0, ~0);
+  writeNode(&outWide[1], elo, ehi, elo, ehi, ~0, ~0);
   nodeLo[0] = lo; nodeHi[0] = hi;
 }
 
@@ -301,13 +342,13 @@ void BvhBuilder::release()
   m_capacity = 0;
 }
 
-hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, int nodeBase, int leafMode, int leafBase)
+hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase)
 {
   const int block = 256;
   const int grid  = (count + block - 1) / block;
   if (count == 1)
   {
-    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, m_nodeLo, m_nodeHi, leafMode, leafBase);
+    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, outWide, m_nodeLo, m_nodeHi, leafMode, leafBase);
     // keysOut[0] must still name primitive 0 for emitTriangles
     BVH_CHECK(hipMemsetAsync(m_keysOut, 0, sizeof(unsigned long long), stream));
     return hipGetLastError();
@@ -317,19 +358,19 @@ hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* ou
   BVH_CHECK(hipMemsetAsync(m_tickets, 0, sizeof(unsigned int) * count, stream));
   hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent, m_range);
   hipLaunchKernelGGL(refitKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_primLo, m_primHi, m_left, m_right,
-                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, nodeBase, leafMode, leafBase, m_maxLeaf);
+                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, outWide, nodeBase, leafMode, leafBase, m_maxLeaf);
   return hipGetLastError();
 }
 
 hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
-                                      BvhNode* outNodes, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6])
+                                      BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6])
 {
   BVH_CHECK(reserve(numTriangles));
   const int block = 256;
   const int grid  = (numTriangles + block - 1) / block;
   hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
   hipLaunchKernelGGL(triangleBoxesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, numTriangles, m_primLo, m_primHi, m_bounds);
-  BVH_CHECK(buildFromBoxes(stream, numTriangles, outNodes, nodeBase, 0, triangleBase));
+  BVH_CHECK(buildFromBoxes(stream, numTriangles, outNodes, outWide, nodeBase, 0, triangleBase));
   hipLaunchKernelGGL(emitTrianglesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, m_keysOut, numTriangles, outTriangles + 3 * (size_t) triangleBase, outShadeTriangles + 9 * (size_t) triangleBase);
   BVH_CHECK(hipGetLastError());
   float4 lo, hi;
@@ -341,7 +382,7 @@ hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attribute
   return hipSuccess;
 }
 
-hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, int nodeBase)
+hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase)
 {
   BVH_CHECK(reserve(numInstances));
   const int block = 256;
@@ -350,7 +391,7 @@ hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, 
   BVH_CHECK(hipMemcpyAsync(m_primHi, hostHi, sizeof(float4) * numInstances, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
   hipLaunchKernelGGL(boxBoundsKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, numInstances, m_bounds);
-  BVH_CHECK(buildFromBoxes(stream, numInstances, outNodes, nodeBase, 1, 0));
+  BVH_CHECK(buildFromBoxes(stream, numInstances, outNodes, outWide, nodeBase, 1, 0));
   BVH_CHECK(hipStreamSynchronize(stream)); // hostLo/hostHi may go away
   return hipSuccess;
 }

@@ -92,7 +92,7 @@ struct TwkDevice_t
   DevLight* d_lights = nullptr;
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
-  BvhNode* d_nodes = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
+  BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
   int tlasRoot = 0;
@@ -190,7 +190,7 @@ static int calculateShift(int size) // Device.cpp:1172-1189
 static void refreshParams(TwkDevice dev)
 {
   LaunchParams& p = dev->params;
-  p.nodes = dev->d_nodes; p.triangles = dev->d_triangles; p.shadeTriangles = dev->d_shadeTriangles; p.instances = dev->d_instances;
+  p.nodes = dev->d_nodes; p.wideNodes = dev->d_wideNodes; p.triangles = dev->d_triangles; p.shadeTriangles = dev->d_shadeTriangles; p.instances = dev->d_instances;
   p.attributes = dev->d_attributes; p.indices = dev->d_indices;
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
@@ -482,7 +482,7 @@ int twk_device_destroy(TwkDevice dev)
   for (TimedLaunch& t : dev->timed) { (void) hipEventDestroy(t.start); (void) hipEventDestroy(t.stop); }
   freeDevice(dev->d_camera); freeDevice(dev->d_lights); freeDevice(dev->d_materials);
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
-  freeDevice(dev->d_nodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
+  freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
   freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
@@ -688,10 +688,11 @@ int twk_build(TwkDevice dev)
   const int tlasBase = (int) numNodes;
   numNodes += (size_t) ((numInstances > 1) ? numInstances - 1 : 1);
 
-  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
+  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   HIP_TRY(hipMalloc(&dev->d_attributes, sizeof(TwkTriangleAttributes) * numAttr));
   HIP_TRY(hipMalloc(&dev->d_indices, sizeof(unsigned int) * numIdx));
   HIP_TRY(hipMalloc(&dev->d_nodes, sizeof(BvhNode) * numNodes));
+  HIP_TRY(hipMalloc(&dev->d_wideNodes, sizeof(BvhNode) * 2 * numNodes));
   HIP_TRY(hipMalloc(&dev->d_triangles, sizeof(float4) * 3 * numTris));
   HIP_TRY(hipMalloc(&dev->d_shadeTriangles, sizeof(float4) * 9 * numTris));
   HIP_TRY(hipMalloc(&dev->d_instances, sizeof(DevInstance) * numInstances));
@@ -706,7 +707,7 @@ int twk_build(TwkDevice dev)
   for (GeometryHost& g : dev->geometries)
   {
     HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes + 12 * (size_t) g.attributeBase, dev->d_indices + g.indexBase, g.numTriangles,
-                                        dev->d_nodes + g.nodeBase, g.nodeBase, dev->d_triangles, dev->d_shadeTriangles, g.triangleBase, g.rootBounds));
+                                        dev->d_nodes + g.nodeBase, dev->d_wideNodes + 2 * (size_t) g.nodeBase, g.nodeBase, dev->d_triangles, dev->d_shadeTriangles, g.triangleBase, g.rootBounds));
   }
 
   // instance records + world boxes
@@ -742,7 +743,7 @@ int twk_build(TwkDevice dev)
     boxHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
   }
   HIP_TRY(hipMemcpyAsync(dev->d_instances, records.data(), sizeof(DevInstance) * numInstances, hipMemcpyHostToDevice, dev->stream));
-  HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), numInstances, dev->d_nodes + tlasBase, tlasBase));
+  HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), numInstances, dev->d_nodes + tlasBase, dev->d_wideNodes + 2 * (size_t) tlasBase, tlasBase));
   HIP_TRY(hipStreamSynchronize(dev->stream));
 
   dev->tlasRoot = tlasBase;

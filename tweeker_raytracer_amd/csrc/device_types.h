@@ -106,7 +106,8 @@ struct __attribute__((aligned(16))) BvhNode
 struct LaunchParams
 {
   // scene
-  const BvhNode*     nodes;
+  const BvhNode*     nodes;          // binary nodes (single-ray traversal: query kernel, overflow fallback, tail kernel)
+  const BvhNode*     wideNodes;      // 4-ary nodes, two 64-byte halves per inner node index (persistent trace kernel)
   const float4*      triangles;      // 3 per triangle slot
   const float4*      shadeTriangles; // 9 per triangle slot: the three vertices' vertex, tangent, normal, texcoord
   const DevInstance* instances;

@@ -79,7 +79,7 @@ template<bool COUNT, bool CUTOUT>
 __global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // waves/SIMD; the 24-KiB LDS stacks admit 6 blocks per CU
 traceKernel(LaunchParams p, int depth)
 {
-  __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
+  __shared__ int stackStorage[(TWK_TRACE_STACK_LDS + 1) * TWK_TRACE_BLOCK]; // + 1 dummy row, see the node step
   int* ldsStack = stackStorage + threadIdx.x;
   const int stride = TWK_TRACE_BLOCK;
 
@@ -185,24 +185,36 @@ traceKernel(LaunchParams p, int depth)
       // spilling traverse() (cold path, not taken on the LBVHs of the shipped scenes).
       while (hasRay && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
-        const float4* n = reinterpret_cast<const float4*>(p.nodes + node);
-        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        // one WIDE node = the four grandchildren of binary node `node`: two levels per round of loads
+        const float4* w = reinterpret_cast<const float4*>(p.wideNodes + 2 * (size_t) node);
+        const float4 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
+        const float4 b0 = w[4], b1 = w[5], b2 = w[6], b3 = w[7];
         ++guard;
         if (COUNT) ++nodeCount;
-        float t0, t1;
-        const bool h0 = slabTest(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, res.t, t0);
-        const bool h1 = slabTest(ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, res.t, t1);
-        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-        const bool take0 = h0 && (!h1 || t0 <= t1); // child 0 is next: the only hit, or the nearer of two
-        node = take0 ? c0 : c1;
+        float t0, t1, t2, t3;
+        const bool h0 = slabTest(ray, a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, tmin, res.t, t0);
+        const bool h1 = slabTest(ray, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, tmin, res.t, t1);
+        const bool h2 = slabTest(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tmin, res.t, t2);
+        const bool h3 = slabTest(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, tmin, res.t, t3);
+        int r0 = __float_as_int(a3.x), r1 = __float_as_int(a3.y), r2 = __float_as_int(b3.x), r3 = __float_as_int(b3.y);
+        const float inf = __uint_as_float(0x7f800000u);
+        t0 = h0 ? t0 : inf; t1 = h1 ? t1 : inf; t2 = h2 ? t2 : inf; t3 = h3 ? t3 : inf;
+        // sort the four (entry distance, reference) pairs, misses last: 5 compare-exchanges
+#define TWK_CE(ta, ra, tb, rb) { const bool sw = (tb) < (ta); const float tl = sw ? (tb) : (ta); (tb) = sw ? (ta) : (tb); (ta) = tl; const int rl = sw ? (rb) : (ra); (rb) = sw ? (ra) : (rb); (ra) = rl; }
+        TWK_CE(t0, r0, t1, r1) TWK_CE(t2, r2, t3, r3) TWK_CE(t0, r0, t2, r2) TWK_CE(t1, r1, t3, r3) TWK_CE(t1, r1, t2, r2)
+#undef TWK_CE
+        const int hits = (int) h0 + (int) h1 + (int) h2 + (int) h3;
         bool stop = (guard > (1u << 22));
-        if (h0 && h1)
+        if (hits > 0)
         {
-          retrace = retrace || (sp >= TWK_TRACE_STACK_LDS);
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS - 1) * stride] = take0 ? c1 : c0;
-          ++sp;
+          // nearest child next, the others pushed far-to-near; row TWK_TRACE_STACK_LDS of the LDS stack is a dummy
+          // that absorbs the unconditional stores once the stack is full
+          node = r0;
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r3; retrace = retrace || (hits > 3 && sp >= TWK_TRACE_STACK_LDS); sp += (hits > 3);
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r2; retrace = retrace || (hits > 2 && sp >= TWK_TRACE_STACK_LDS); sp += (hits > 2);
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r1; retrace = retrace || (hits > 1 && sp >= TWK_TRACE_STACK_LDS); sp += (hits > 1);
         }
-        if (!(h0 || h1))
+        else
         {
           stop = stop || (sp == 0);
           sp = max(sp - 1, 0);
@@ -271,7 +283,7 @@ traceKernel(LaunchParams p, int depth)
               setupRay(ray, objOrg, objDir);
               currentInstance = payload;
               retrace = retrace || (sp >= TWK_TRACE_STACK_LDS);
-              ldsStack[min(sp, TWK_TRACE_STACK_LDS - 1) * stride] = TWK_BVH_SENTINEL;
+              ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = TWK_BVH_SENTINEL;
               ++sp;
               node = __float_as_int(r3.x);
               if (retrace) { hasRay = false; done = true; }
