@@ -136,6 +136,7 @@ typedef struct TwkLaunchStats
   uint64_t tailNodesVisited;
   uint64_t tailTrianglesTested;
   uint64_t tailInstancesEntered;
+  uint64_t overflowRays;    /* rays whose LDS traversal stack overflowed and were re-traced with the HBM-backed stack */
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */
@@ -229,7 +230,8 @@ int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma /*3 per px*/, int
 
 /* Closest-hit / any-hit query of arbitrary rays through the device BVH (≙ optixTrace contract,
  * raygeneration.cu:84-89, closesthit.cu:281-286). rays: 8 floats each (o.xyz, tmin, d.xyz, tmax).
- * out: t, beta, gamma per ray; ids: instance, primitive (or -1). anyHit != 0: ids[0] = 1 if occluded. */
+ * out: t, beta, gamma per ray; ids: instance, primitive (or -1). anyHit != 0: ids[0] = 1 if occluded.
+ * Geometric query: cutout opacity is not applied here. */
 int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids);
 
 /* Unit taps of the device math used by the shaders (bit-exact parity with the oracle):

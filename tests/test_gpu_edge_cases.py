@@ -1,0 +1,144 @@
+"""-m gpu: edge cases of the optixTrace contract through the device BVH — tiny geometries (1, 2, 3, 5 triangles:
+single-leaf node, top-level inline test, just above the inline threshold), degenerate triangles, sheared / mirrored
+instance transforms, coincident geometry (ties → smallest instance, primitive) and a scene built to overflow the
+LDS traversal stack. All against the oracle's brute force, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _attrs(verts):
+    """TriangleAttributes from positions: tangent x, normal z, texcoord = position.xy."""
+    verts = np.asarray(verts, np.float32).reshape(-1, 3)
+    a = np.zeros((verts.shape[0], 12), np.float32)
+    a[:, 0:3] = verts
+    a[:, 3] = 1.0
+    a[:, 8] = 1.0
+    a[:, 9:11] = verts[:, 0:2]
+    return a
+
+
+def _state(twk, w, h, depth=2):
+    st = twk.DeviceState()
+    st.resolution[0], st.resolution[1] = w, h
+    st.tileSize[0], st.tileSize[1] = 8, 8
+    st.pathLengths[0], st.pathLengths[1] = 1, depth
+    st.distribution, st.samplesSqrt, st.lensShader = 0, 1, 0
+    st.epsilonFactor, st.envRotation, st.clockFactor = 500.0, 0.0, 1000.0
+    return st
+
+
+def _material(twk, bsdf=0, albedo=(0.7, 0.6, 0.5)):
+    m = twk.MaterialGUI()
+    m.indexBSDF = bsdf
+    m.albedo[0], m.albedo[1], m.albedo[2] = albedo
+    m.absorptionColor[0] = m.absorptionColor[1] = m.absorptionColor[2] = 1.0
+    m.absorptionScale, m.ior, m.thinwalled = 0.0, 1.5, 0
+    m.useAlbedoTexture = m.useCutoutTexture = 0
+    m.roughness[0] = m.roughness[1] = 0.1
+    return m
+
+
+def _pair(twk, orc, geometries, instances, w=48, h=32, depth=2, miss=1):
+    """geometries: list of (attrs, indices); instances: list of (geometry, 3x4 transform, material)."""
+    cam = twk.camera_frustum((0.0, 0.0, 0.0), 0.75, 0.5, 50.0, 6.0, w / h)
+    light = twk.LightDefinition()
+    light.type = 0
+    light.area = 12.566371
+    light.emission[0] = light.emission[1] = light.emission[2] = 1.0
+    mats = [_material(twk), _material(twk, 1, (0.9, 0.9, 0.9)), _material(twk, 3, (0.8, 0.7, 0.3))]
+    out = []
+    for make in (lambda: twk.Device(ordinal=0, miss=miss), lambda: orc.Oracle(miss=miss)):
+        r = make()
+        r.setState(_state(twk, w, h, depth))
+        r.initCameras([cam])
+        r.initLights([light])
+        r.initMaterials(mats)
+        for a, i in geometries:
+            r.addGeometry(a, i)
+        for g, t, m in instances:
+            r.addInstance(g, t, m)
+        r.build()
+        out.append(r)
+    return out
+
+
+IDENT = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]
+
+
+def _rays(n, seed, spread=2.5):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+    o[:, 2] = rng.uniform(2.0, 5.0, n)
+    d = (rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32) - o * np.float32(0.6)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, np.full((n, 1), 1e-4, np.float32), d.astype(np.float32), np.full((n, 1), 1e27, np.float32)], 1).astype(np.float32)
+
+
+def _compare(dev, ref, rays):
+    ref.setTraceMode(False)  # brute force
+    g, o = dev.traceRays(rays), ref.traceRays(rays)
+    assert np.array_equal(g[1], o[1]), "ids differ"
+    hit = o[1][:, 0] >= 0
+    assert np.array_equal(_bits(g[0][hit]), _bits(o[0][hit]))
+    ga, oa = dev.traceRays(rays, anyHit=True), ref.traceRays(rays, anyHit=True)
+    assert np.array_equal(ga[1][:, 0], oa[1][:, 0])
+    return hit
+
+
+def test_tiny_and_degenerate_geometries(twk, orc):
+    rng = np.random.default_rng(5)
+    geos = []
+    for ntri in (1, 2, 3, 5, 9):
+        v = rng.uniform(-1, 1, (ntri * 3, 3)).astype(np.float32)
+        geos.append((_attrs(v), np.arange(ntri * 3, dtype=np.uint32)))
+    # degenerate: zero-area triangle, repeated vertex, plus one proper triangle sharing an edge with a sliver
+    v = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0],  [0, 0, 0], [0, 0, 0], [1, 1, 0],  [-1, -1, 0.5], [1, -1, 0.5], [0, 1, 0.5],
+                  [-1, -1, 0.5], [0, 1, 0.5], [-1, -1 + 1e-7, 0.5]], np.float32)
+    geos.append((_attrs(v), np.arange(12, dtype=np.uint32)))
+    inst = []
+    for g in range(len(geos)):
+        t = np.array(IDENT, np.float32).reshape(3, 4)
+        t[:, 3] = [(g % 3 - 1) * 2.2, (g // 3 - 0.5) * 2.2, 0]
+        inst.append((g, t.reshape(-1), g % 3))
+    # sheared, non-uniformly scaled and mirrored instances of the 5-triangle geometry
+    inst.append((3, [1.5, 0.4, 0, 0.3, 0, 0.7, 0.2, -0.2, 0.1, 0, -1.2, 0.5], 0))
+    inst.append((3, [-1, 0, 0, -0.5, 0, 1, 0, 0.4, 0, 0, 1, -0.8], 2))
+    dev, ref = _pair(twk, orc, geos, inst)
+    hit = _compare(dev, ref, _rays(6000, 1))
+    assert 0.05 < hit.mean() < 0.95
+    for it in range(2):
+        dev.render(it)
+        ref.render(it)
+    assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(ref.getOutputBufferHost()))
+    dev.close()
+
+
+def test_coincident_geometry_ties_and_lds_stack_overflow(twk, orc):
+    """64 coincident instances of 4096 coincident triangles: every box of every level is hit, the wide-node step
+    pushes three entries per level and the 24-entry LDS stack overflows; the rays are re-traced by
+    traceOverflowKernel. All candidates tie in t: the smallest (instance, primitive) must win on both sides."""
+    tri = np.array([[-1.5, -1.2, 0], [1.5, -1.2, 0], [0, 1.6, 0]], np.float32)
+    ntri = 4096
+    geo = (_attrs(np.tile(tri, (ntri, 1))), np.arange(ntri * 3, dtype=np.uint32))
+    inst = [(0, IDENT, i % 3) for i in range(64)]
+    dev, ref = _pair(twk, orc, [geo], inst, w=8, h=8, depth=2)
+    rays = _rays(64, 3, spread=0.6)
+    hit = _compare(dev, ref, rays)
+    assert hit.any()
+    g = dev.traceRays(rays)
+    assert (g[1][hit] == 0).all(), "ties must resolve to instance 0, primitive 0"
+    dev.statsEnable(True)
+    dev.statsGet(True)
+    for it in range(2):
+        dev.render(it)
+        ref.render(it)
+    st = dev.statsGet(True)
+    assert st["overflowRays"] > 0, "the scene is built to overflow the LDS stack"
+    assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(ref.getOutputBufferHost()))
+    dev.close()

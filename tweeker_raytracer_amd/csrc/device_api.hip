@@ -137,6 +137,14 @@ static int activate(TwkDevice dev, const char* where, bool flush = true)
 
 template<typename T> static void freeDevice(T*& p) { if (p) { (void) hipFree(p); p = nullptr; } }
 
+// Scratch device allocation of one call; freed on every return path.
+template<typename T> struct ScopedDeviceBuffer
+{
+  T* ptr = nullptr;
+  ~ScopedDeviceBuffer() { if (ptr) (void) hipFree(ptr); }
+  hipError_t allocate(size_t count) { return hipMalloc(&ptr, count * sizeof(T)); }
+};
+
 // Inverse of a row-major 3x4 affine matrix in double, rounded once (OptiX derives the same matrix for
 // optixGetInstanceInverseTransformFromHandle, closesthit.cu:49-52).
 static void invertAffine(const float m[12], float inv[12])
@@ -892,7 +900,7 @@ int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
   HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
-  stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11];
+  stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }
@@ -960,18 +968,17 @@ int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit,
   if (!dev->stateSet) { dev->launchWidth = 1; }
   if ((rc = ensureStreams(dev))) return rc;
   refreshParams(dev);
-  float* d_rays = nullptr; float* d_out = nullptr; int* d_ids = nullptr;
-  HIP_TRY(hipMalloc(&d_rays, numRays * 8 * sizeof(float)));
-  HIP_TRY(hipMalloc(&d_out, numRays * 3 * sizeof(float)));
-  HIP_TRY(hipMalloc(&d_ids, numRays * 2 * sizeof(int)));
-  HIP_TRY(hipMemcpyAsync(d_rays, rays, numRays * 8 * sizeof(float), hipMemcpyHostToDevice, dev->stream));
+  ScopedDeviceBuffer<float> d_rays, d_out; ScopedDeviceBuffer<int> d_ids;
+  HIP_TRY(d_rays.allocate(numRays * 8));
+  HIP_TRY(d_out.allocate(numRays * 3));
+  HIP_TRY(d_ids.allocate(numRays * 2));
+  HIP_TRY(hipMemcpyAsync(d_rays.ptr, rays, numRays * 8 * sizeof(float), hipMemcpyHostToDevice, dev->stream));
   int grid = (int) ((numRays + TWK_TRACE_BLOCK - 1) / TWK_TRACE_BLOCK);
   if (grid > traceGridBlocks(dev)) grid = traceGridBlocks(dev);
-  launchTraceQuery(dev->params, d_rays, (unsigned int) numRays, anyHit, d_out, d_ids, grid, dev->stream);
-  HIP_TRY(hipMemcpyAsync(tBetaGamma, d_out, numRays * 3 * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
-  HIP_TRY(hipMemcpyAsync(ids, d_ids, numRays * 2 * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+  launchTraceQuery(dev->params, d_rays.ptr, (unsigned int) numRays, anyHit, d_out.ptr, d_ids.ptr, grid, dev->stream);
+  HIP_TRY(hipMemcpyAsync(tBetaGamma, d_out.ptr, numRays * 3 * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
+  HIP_TRY(hipMemcpyAsync(ids, d_ids.ptr, numRays * 2 * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  (void) hipFree(d_rays); (void) hipFree(d_out); (void) hipFree(d_ids);
   return TWK_SUCCESS;
 }
 
@@ -980,16 +987,15 @@ int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float*
   int rc = activate(dev, "twk_debug_math"); if (rc) return rc;
   if (op < 0 || op > 7 || !x || !out || (op == 3 && !y)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_math: bad arguments");
   if (n == 0) return TWK_SUCCESS;
-  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(&dx, n * sizeof(float)));
-  HIP_TRY(hipMalloc(&dy, n * sizeof(float)));
-  HIP_TRY(hipMalloc(&dout, n * sizeof(float)));
-  HIP_TRY(hipMemcpyAsync(dx, x, n * sizeof(float), hipMemcpyHostToDevice, dev->stream));
-  HIP_TRY(hipMemcpyAsync(dy, y ? y : x, n * sizeof(float), hipMemcpyHostToDevice, dev->stream));
-  launchMathTap(op, dx, dy, dout, n, dev->stream);
-  HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
+  ScopedDeviceBuffer<float> dx, dy, dout;
+  HIP_TRY(dx.allocate(n));
+  HIP_TRY(dy.allocate(n));
+  HIP_TRY(dout.allocate(n));
+  HIP_TRY(hipMemcpyAsync(dx.ptr, x, n * sizeof(float), hipMemcpyHostToDevice, dev->stream));
+  HIP_TRY(hipMemcpyAsync(dy.ptr, y ? y : x, n * sizeof(float), hipMemcpyHostToDevice, dev->stream));
+  launchMathTap(op, dx.ptr, dy.ptr, dout.ptr, n, dev->stream);
+  HIP_TRY(hipMemcpyAsync(out, dout.ptr, n * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  (void) hipFree(dx); (void) hipFree(dy); (void) hipFree(dout);
   return TWK_SUCCESS;
 }
 

@@ -447,6 +447,7 @@ traceOverflowKernel(LaunchParams p, int depth)
   if (COUNT)
   {
     // the persistent kernel already counted these rays and its partial visits; add the re-trace's visits
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.stats[12], (unsigned long long) count);
     atomicAdd(&p.stats[2], (unsigned long long) nodeCount);
     atomicAdd(&p.stats[3], (unsigned long long) triCount);
     atomicAdd(&p.stats[4], (unsigned long long) instCount);
