@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    for k in ("traceKernel<false>", "traceKernel<true>", "shadeKernel", "generateKernel", "accumulateKernel"):
+    for k in ("traceKernel<false, false>", "traceKernel<false, true>", "traceKernel<true", "traceKernel<false>", "shadeKernel", "generateKernel", "accumulateKernel"):
         if k in name:
             return k
     return None

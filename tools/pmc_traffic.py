@@ -9,7 +9,7 @@ root, out = sys.argv[1], sys.argv[2]
 acc = {}
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
-        if "traceKernel<false>" not in r["Kernel_Name"]:
+        if "traceKernel<false" not in r["Kernel_Name"]:
             continue
         c = r["Counter_Name"]
         if c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"):

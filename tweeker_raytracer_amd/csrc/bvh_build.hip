@@ -164,8 +164,7 @@ TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const 
   p[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
 }
 
-// Wide (4-ary) node of inner node i = the children of its children, stored as TWO 64-byte halves in the BVH2 node
-// format (two boxes + two references each): a traversal step over a wide node crosses two levels of the binary tree
+// Wide (4-ary) node of inner node i = the children of its children, 128 bytes (layout at writeWideNode): a traversal step over a wide node crosses two levels of the binary tree
 // with one round of loads instead of two dependent ones. A child that is a leaf occupies one entry; unused entries
 // get an empty box. Wide nodes share the index space of the binary nodes (every inner node has one; only those at
 // even depth below the root are ever visited).
@@ -189,10 +188,21 @@ TWK_D void expandChild(const BvhNode* outNodes, int nodeBase, int ref, const flo
   e[n].lo = make_float4(c1.z, c1.w, c2.x, 0.0f); e[n].hi = make_float4(c2.y, c2.z, c2.w, 0.0f); e[n].ref = __float_as_int(c3.y); ++n;
 }
 
+// Wide node layout, 8 float4: (lo_k.xyz, ref_k) and (hi_k.xyz, unused) for k = 0..3, with the four references in
+// the .w of the FIRST four float4 — (lo0,ref0) (hi0,ref1) (lo1,ref2) (hi1,ref3) (lo2,-) (hi2,-) (lo3,-) (hi3,-) —
+// so that they arrive with the box data the first slab tests need. (With the references in a float4 of their own
+// the compiler sank those loads behind the box tests: two extra dependent L2 round trips per traversal step.)
 TWK_D void writeWideNode(BvhNode* wide, const WideEntry* e)
 {
-  writeNode(&wide[0], e[0].lo, e[0].hi, e[1].lo, e[1].hi, e[0].ref, e[1].ref);
-  writeNode(&wide[1], e[2].lo, e[2].hi, e[3].lo, e[3].hi, e[2].ref, e[3].ref);
+  float4* p = reinterpret_cast<float4*>(wide);
+  p[0] = make_float4(e[0].lo.x, e[0].lo.y, e[0].lo.z, __int_as_float(e[0].ref));
+  p[1] = make_float4(e[0].hi.x, e[0].hi.y, e[0].hi.z, __int_as_float(e[1].ref));
+  p[2] = make_float4(e[1].lo.x, e[1].lo.y, e[1].lo.z, __int_as_float(e[2].ref));
+  p[3] = make_float4(e[1].hi.x, e[1].hi.y, e[1].hi.z, __int_as_float(e[3].ref));
+  p[4] = make_float4(e[2].lo.x, e[2].lo.y, e[2].lo.z, 0.0f);
+  p[5] = make_float4(e[2].hi.x, e[2].hi.y, e[2].hi.z, 0.0f);
+  p[6] = make_float4(e[3].lo.x, e[3].lo.y, e[3].lo.z, 0.0f);
+  p[7] = make_float4(e[3].hi.x, e[3].hi.y, e[3].hi.z, 0.0f);
 }
 
 // One thread per leaf walks up; the second thread to arrive at an inner node (ticket == 1) owns it.
@@ -270,8 +280,10 @@ __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4
   const float inf = __uint_as_float(0x7f800000u);
   const float4 elo = make_float4(inf, inf, inf, 0.0f), ehi = make_float4(inf, inf, inf, 0.0f); // never hit, see emptyEntry()
   writeNode(&outNodes[0], lo, hi, elo, ehi, (leafMode == 0) ? ~leafBase : ~0, ~0);
-  writeNode(&outWide[0], lo, hi, elo, ehi, (leafMode == 0) ? ~leafBase : ~0, ~0);
-  writeNode(&outWide[1], elo, ehi, elo, ehi, ~0, ~0);
+  WideEntry e[4];
+  e[0].lo = lo; e[0].hi = hi; e[0].ref = (leafMode == 0) ? ~leafBase : ~0;
+  emptyEntry(e[1]); emptyEntry(e[2]); emptyEntry(e[3]);
+  writeWideNode(outWide, e);
   nodeLo[0] = lo; nodeHi[0] = hi;
 }
 

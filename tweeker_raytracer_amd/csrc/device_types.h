@@ -107,7 +107,7 @@ struct LaunchParams
 {
   // scene
   const BvhNode*     nodes;          // binary nodes (single-ray traversal: query kernel, overflow fallback, tail kernel)
-  const BvhNode*     wideNodes;      // 4-ary nodes, two 64-byte halves per inner node index (persistent trace kernel)
+  const BvhNode*     wideNodes;      // 4-ary nodes, 128 bytes = 2 BvhNode slots per inner node index (persistent trace kernel; layout: bvh_build.hip writeWideNode)
   const float4*      triangles;      // 3 per triangle slot
   const float4*      shadeTriangles; // 9 per triangle slot: the three vertices' vertex, tangent, normal, texcoord
   const DevInstance* instances;

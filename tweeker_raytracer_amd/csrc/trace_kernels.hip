@@ -187,16 +187,18 @@ traceKernel(LaunchParams p, int depth)
       {
         // one WIDE node = the four grandchildren of binary node `node`: two levels per round of loads
         const float4* w = reinterpret_cast<const float4*>(p.wideNodes + 2 * (size_t) node);
-        const float4 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
-        const float4 b0 = w[4], b1 = w[5], b2 = w[6], b3 = w[7];
+        const float4 l0 = w[0], u0 = w[1], l1 = w[2], u1 = w[3], l2 = w[4], u2 = w[5], l3 = w[6], u3 = w[7];
         ++guard;
         if (COUNT) ++nodeCount;
+        int r0 = __float_as_int(l0.w), r1 = __float_as_int(u0.w), r2 = __float_as_int(l1.w), r3 = __float_as_int(u1.w);
+        // Pin the references here: left alone, hipcc narrows the node loads to dwordx3 and fetches the four references
+        // with separate dword loads AFTER the box tests — two more dependent L2 round trips per traversal step.
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
         float t0, t1, t2, t3;
-        const bool h0 = slabTest(ray, a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, tmin, res.t, t0);
-        const bool h1 = slabTest(ray, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, tmin, res.t, t1);
-        const bool h2 = slabTest(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tmin, res.t, t2);
-        const bool h3 = slabTest(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, tmin, res.t, t3);
-        int r0 = __float_as_int(a3.x), r1 = __float_as_int(a3.y), r2 = __float_as_int(b3.x), r3 = __float_as_int(b3.y);
+        const bool h0 = slabTest(ray, l0.x, l0.y, l0.z, u0.x, u0.y, u0.z, tmin, res.t, t0);
+        const bool h1 = slabTest(ray, l1.x, l1.y, l1.z, u1.x, u1.y, u1.z, tmin, res.t, t1);
+        const bool h2 = slabTest(ray, l2.x, l2.y, l2.z, u2.x, u2.y, u2.z, tmin, res.t, t2);
+        const bool h3 = slabTest(ray, l3.x, l3.y, l3.z, u3.x, u3.y, u3.z, tmin, res.t, t3);
         const float inf = __uint_as_float(0x7f800000u);
         t0 = h0 ? t0 : inf; t1 = h1 ? t1 : inf; t2 = h2 ? t2 : inf; t3 = h3 ? t3 : inf;
         // sort the four (entry distance, reference) pairs, misses last: 5 compare-exchanges
