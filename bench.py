@@ -201,7 +201,7 @@ def main():
             except Exception:
                 traffic = None
         result["roofline"] = {
-            "kernel": "twk::traceKernel<false>",
+            "kernel": "twk::traceKernel<false, false>",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,

@@ -17,7 +17,7 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 per = {c: v[0] / max(1, len(v[1])) for c, v in acc.items()}
 res = {
-    "kernel": "twk::traceKernel<false>",
+    "kernel": "twk::traceKernel<false, false>",
     "dispatches": len(acc["FETCH_SIZE"][1]),
     "fetch_size_kib_per_launch": per["FETCH_SIZE"],
     "write_size_kib_per_launch": per["WRITE_SIZE"],

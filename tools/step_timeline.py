@@ -2,7 +2,7 @@
 """Print the per-kernel timeline of one step from a rocprofv3 kernel trace CSV."""
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
-sel = [r for r in rows if any(k in r['Kernel_Name'] for k in ('traceKernel<false>', 'shadeKernel', 'generateKernel', 'accumulateKernel'))]
+sel = [r for r in rows if any(k in r['Kernel_Name'] for k in ('traceKernel<false', 'shadeKernel', 'generateKernel', 'accumulateKernel'))]
 gi = [i for i, r in enumerate(sel) if 'generate' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(gi) // 2
 i0, i1 = gi[k], gi[k + 1]
