@@ -233,6 +233,10 @@ traceKernel(LaunchParams p, int depth)
       if (hasRay && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
       {
         bool pop = false;
+        // Triangle range this lane tests in this round: the slots of a bottom-level leaf, or all triangles of a small
+        // geometry tested right at its top-level leaf. ONE copy of the triangle loop serves both kinds of lanes.
+        int triFirst = 0, triLast = -1, triInstance = currentInstance;
+        V3 triOrg = ray.o; // object-space origin (inside an instance ray.o is the transformed origin)
         if (node == TWK_BVH_SENTINEL)
         {
           setupRay(ray, org, dir); // back to the world-space ray
@@ -257,28 +261,10 @@ traceKernel(LaunchParams p, int depth)
             const int triCountInst = __float_as_int(r3.z);
             if (triCountInst <= TWK_INLINE_TRIANGLES)
             {
-              // small geometry: test its triangles here, stay in the top level (no descent, no sentinel)
-              const int first = __float_as_int(r3.y);
+              // small geometry: its triangles are tested here, the lane stays in the top level (no descent, no sentinel)
+              triFirst = __float_as_int(r3.y); triLast = triFirst + triCountInst - 1;
+              triInstance = payload; triOrg = objOrg;
               pop = true;
-              for (int ts = first; ts < first + triCountInst; ++ts)
-              {
-                const float4* tri = p.triangles + 3 * (size_t) ts;
-                const float4 a = tri[0], b = tri[1], c = tri[2];
-                if (COUNT) ++triCount;
-                float t, beta, gamma;
-                if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
-                {
-                  const int prim = __float_as_int(a.w);
-                  const bool closer = (t < res.t) ||
-                                      (t == res.t && res.instance >= 0 &&
-                                       (payload < res.instance || (payload == res.instance && prim < res.primitive)));
-                  if (closer)
-                  {
-                    res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim; res.triangleSlot = ts;
-                    if (anyHit) { pop = false; hasRay = false; done = true; break; }
-                  }
-                }
-              }
             }
             else
             {
@@ -294,29 +280,31 @@ traceKernel(LaunchParams p, int depth)
           else
           {
             // a leaf of 1..8 consecutive triangle slots
-            const int first = payload & 0x0fffffff, last = first + (payload >> 28);
+            triFirst = payload & 0x0fffffff; triLast = triFirst + (payload >> 28);
             pop = true;
-            for (int ts = first; ts <= last; ++ts)
+          }
+        }
+
+        for (int ts = triFirst; ts <= triLast; ++ts)
+        {
+          const float4* tri = p.triangles + 3 * (size_t) ts;
+          const float4 a = tri[0], b = tri[1], c = tri[2];
+          if (COUNT) ++triCount;
+          float t, beta, gamma;
+          if (woopIntersect(woop, triOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
+          {
+            const int prim = __float_as_int(a.w);
+            const bool closer = (t < res.t) ||
+                                (t == res.t && res.instance >= 0 &&
+                                 (triInstance < res.instance || (triInstance == res.instance && prim < res.primitive)));
+            if (closer)
             {
-              const float4* tri = p.triangles + 3 * (size_t) ts;
-              const float4 a = tri[0], b = tri[1], c = tri[2];
-              if (COUNT) ++triCount;
-              float t, beta, gamma;
-              if (woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
-              {
-                const int prim = __float_as_int(a.w);
-                const bool closer = (t < res.t) ||
-                                    (t == res.t && res.instance >= 0 &&
-                                     (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
-                if (closer)
-                {
-                  res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim; res.triangleSlot = ts;
-                  if (anyHit) { pop = false; hasRay = false; done = true; break; }
-                }
-              }
+              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = triInstance; res.primitive = prim; res.triangleSlot = ts;
+              if (anyHit) { pop = false; hasRay = false; done = true; break; }
             }
           }
         }
+
         if (pop)
         {
           if (sp == 0) { hasRay = false; done = true; }
