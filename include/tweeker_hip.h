@@ -196,7 +196,7 @@ int twk_clear_scene(TwkDevice dev);
 int twk_launch(TwkDevice dev, unsigned int iterationIndex);
 int twk_sync(TwkDevice dev);                                  /* ≙ Device::synchronizeStream */
 /* twk_launch is asynchronous and deferred: consecutive iteration indices are rendered together, up to `iterations`
- * samples per pixel per wavefront pass (default 8), as soon as the batch is full or any other call observes the
+ * samples per pixel per wavefront pass (default 16), as soon as the batch is full or any other call observes the
  * device. The image is bit-identical to one pass per iteration; 1 restores strict one-launch-per-call behaviour. */
 int twk_set_launch_batch(TwkDevice dev, int iterations);
 

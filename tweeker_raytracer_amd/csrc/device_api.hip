@@ -116,7 +116,7 @@ struct TwkDevice_t
   int   tailDepth = 0; // > 0: bounces >= tailDepth run in the tail kernel (TWK_TAIL_DEPTH); measured no faster than the wavefront at 1920x1080, kept off
   // Deferred launches: twk_launch only records the iteration; consecutive iterations are rendered together as one
   // wavefront pass of up to batchMax samples per pixel when the batch is full or anything observes the device.
-  int   batchMax = 8;
+  int   batchMax = 16;
   unsigned int pendingFirst = 0;
   int   pendingCount = 0;
   int   allocatedPaths = 0;
