@@ -214,6 +214,11 @@ def main():
             "rays_per_step": rays / args.steps,
             "nodes_per_ray": st["nodesVisited"] / max(1, rays),
             "triangles_per_ray": st["trianglesTested"] / max(1, rays),
+            "lane_occupancy": {"node_step": st["nodesVisited"] / max(1, 64 * st["nodeWaveSteps"]),
+                               "triangle_test": st["trianglesTested"] / max(1, 64 * st["triangleWaveSteps"]),
+                               "node_wave_steps_per_launch": st["nodeWaveSteps"] / max(1, trace_launches),
+                               "triangle_wave_steps_per_launch": st["triangleWaveSteps"] / max(1, trace_launches),
+                               "leaf_wave_steps_per_launch": st["leafWaveSteps"] / max(1, trace_launches)},
             "Mrays_per_s": rays / (trace_ms * 1.0e-3) / 1.0e6 if trace_ms > 0 else 0.0,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         }

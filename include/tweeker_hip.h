@@ -137,6 +137,9 @@ typedef struct TwkLaunchStats
   uint64_t tailTrianglesTested;
   uint64_t tailInstancesEntered;
   uint64_t overflowRays;    /* rays whose LDS traversal stack overflowed and were re-traced with the HBM-backed stack */
+  uint64_t nodeWaveSteps;     /* wave-level iterations of the node step: lane occupancy there = nodesVisited / (64 * nodeWaveSteps) */
+  uint64_t triangleWaveSteps; /* wave-level iterations of the triangle test */
+  uint64_t leafWaveSteps;     /* wave-level executions of the leaf / instance entry / instance exit step */
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */

@@ -57,7 +57,8 @@ class LaunchStats(C.Structure):
                 ("trianglesTested", C.c_uint64), ("instancesEntered", C.c_uint64), ("shadedHits", C.c_uint64),
                 ("missed", C.c_uint64), ("maxNodesPerRay", C.c_uint64), ("tailRays", C.c_uint64),
                 ("tailNodesVisited", C.c_uint64), ("tailTrianglesTested", C.c_uint64), ("tailInstancesEntered", C.c_uint64),
-                ("overflowRays", C.c_uint64)]
+                ("overflowRays", C.c_uint64),
+                ("nodeWaveSteps", C.c_uint64), ("triangleWaveSteps", C.c_uint64), ("leafWaveSteps", C.c_uint64)]
 
 
 class AppInfo(C.Structure):

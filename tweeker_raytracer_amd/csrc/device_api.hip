@@ -901,6 +901,7 @@ int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
   stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
+  stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }

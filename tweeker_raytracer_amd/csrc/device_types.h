@@ -170,7 +170,9 @@ struct LaunchParams
 #define TWK_COUNTERS_PER_DEPTH 4
 #define TWK_MAX_DEPTH 64
 
+#ifndef TWK_TRACE_STACK_LDS
 #define TWK_TRACE_STACK_LDS   24  // entries per lane in LDS
+#endif
 #define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
 #define TWK_TRACE_BLOCK       256
 #define TWK_TRACE_TICKET      64   // queue slots per wave ticket (coarser tickets starve the chip: a launch holds only ~18 groups per wave)

@@ -93,6 +93,8 @@ traceKernel(LaunchParams p, int depth)
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
   unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0, maxSteps = 0;
+  unsigned int nodeWaveSteps = 0, triWaveSteps = 0, leafWaveSteps = 0; // COUNT: wave-level iterations, tallied by the first active lane (lane occupancy = lane count / (64 * wave steps))
+#define TWK_WAVE_STEP(counter) if (COUNT) { if (lane == (unsigned int) (__ffsll((long long) __ballot(true)) - 1)) ++(counter); }
 
   // Wave-uniform pool of queue slots. Most of the queue is handed out statically: wave w owns the contiguous range
   // [w * S, (w + 1) * S) with S = 3/4 of its fair share (a multiple of 64), the last quarter is dealt dynamically in
@@ -190,6 +192,7 @@ traceKernel(LaunchParams p, int depth)
         const float4 l0 = w[0], u0 = w[1], l1 = w[2], u1 = w[3], l2 = w[4], u2 = w[5], l3 = w[6], u3 = w[7];
         ++guard;
         if (COUNT) ++nodeCount;
+        TWK_WAVE_STEP(nodeWaveSteps)
         int r0 = __float_as_int(l0.w), r1 = __float_as_int(u0.w), r2 = __float_as_int(l1.w), r3 = __float_as_int(u1.w);
         // Pin the references here: left alone, hipcc narrows the node loads to dwordx3 and fetches the four references
         // with separate dword loads AFTER the box tests — two more dependent L2 round trips per traversal step.
@@ -233,6 +236,7 @@ traceKernel(LaunchParams p, int depth)
       if (hasRay && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
       {
         bool pop = false;
+        TWK_WAVE_STEP(leafWaveSteps)
         // Triangle range this lane tests in this round: the slots of a bottom-level leaf, or all triangles of a small
         // geometry tested right at its top-level leaf. ONE copy of the triangle loop serves both kinds of lanes.
         int triFirst = 0, triLast = -1, triInstance = currentInstance;
@@ -290,6 +294,7 @@ traceKernel(LaunchParams p, int depth)
           const float4* tri = p.triangles + 3 * (size_t) ts;
           const float4 a = tri[0], b = tri[1], c = tri[2];
           if (COUNT) ++triCount;
+          TWK_WAVE_STEP(triWaveSteps)
           float t, beta, gamma;
           if (woopIntersect(woop, triOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
           {
@@ -381,7 +386,11 @@ traceKernel(LaunchParams p, int depth)
     atomicAdd(&p.stats[3], (unsigned long long) triCount);
     atomicAdd(&p.stats[4], (unsigned long long) instCount);
     atomicMax(&p.stats[7], (unsigned long long) maxSteps);
+    if (nodeWaveSteps) atomicAdd(&p.stats[13], (unsigned long long) nodeWaveSteps);
+    if (triWaveSteps)  atomicAdd(&p.stats[14], (unsigned long long) triWaveSteps);
+    if (leafWaveSteps) atomicAdd(&p.stats[15], (unsigned long long) leafWaveSteps);
   }
+#undef TWK_WAVE_STEP
 }
 
 // Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again
