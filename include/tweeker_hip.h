@@ -217,6 +217,25 @@ int twk_set_output_device_pointer(TwkDevice dev, void* dptr, size_t bytes);
  * `output` the full W×H RGBA32F image (device memory). Runs on this handle's stream. */
 int twk_compositor(TwkDevice dev, const void* tiles, void* output);
 
+/* ≙ TonemapperGUI (inc/TonemapperGUI.h:34-43), same field order. Neutral defaults: gamma 1, whitePoint 1,
+ * colorBalance 1 1 1, burnHighlights 1, crushBlacks 0, saturation 1, brightness 1 (Application.cpp:111-120). */
+typedef struct TwkTonemapper
+{
+  float gamma;
+  float whitePoint;
+  float colorBalance[3];
+  float burnHighlights;
+  float crushBlacks;
+  float saturation;
+  float brightness;
+} TwkTonemapper;
+
+/* ≙ the tonemapper loop of Application::screenshot (Application.cpp:2259-2297), as the device kernel its authors
+ * ask for there: RGBA32F → RGB8, pixel i at rgb8Host[3*i..3*i+2], same row order as the input.
+ * rgbaDevice NULL: the handle's own accumulation buffer (numPixels must be launchWidth*height); otherwise any
+ * device buffer of numPixels float4 (e.g. the composited multi-GPU image). Synchronises the handle's stream. */
+int twk_tonemap(TwkDevice dev, const TwkTonemapper* tm, const void* rgbaDevice, size_t numPixels, unsigned char* rgb8Host);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 int twk_profile_enable(TwkDevice dev, int enable);   /* hipEvent pair around every kernel launch */
 int twk_profile_reset(TwkDevice dev);
@@ -238,7 +257,7 @@ int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma /*3 per px*/, int
 int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids);
 
 /* Unit taps of the device math used by the shaders (bit-exact parity with the oracle):
- * op 0 sin, 1 cos, 2 exp, 3 atan2(x[i], y[i]), 4 acos, 5 atan, 6 sqrt, 7 1/x. */
+ * op 0 sin, 1 cos, 2 exp, 3 atan2(x[i], y[i]), 4 acos, 5 atan, 6 sqrt, 7 1/x, 8 log, 9 pow(x[i], y[i]). */
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n);
 
 /* ---- host scene layer (rtigo3 Application: description files, meshes, camera) -------------- */
@@ -272,6 +291,18 @@ int twk_app_get_instance(TwkApp app, int idInstance, int* idGeometry, float tran
 /* Runs the reference's init sequence on a device: setState, initCameras, initLights, initMaterials,
  * initScene (Application.cpp:303,328-332). */
 int twk_app_init_device(TwkApp app, TwkDevice dev);
+/* Tonemapper settings of the system description ("gamma", "colorBalance", "whitePoint", "burnHighlights",
+ * "crushBlacks", "saturation", "brightness", Application.cpp:1244-1292). */
+int twk_app_get_tonemapper(TwkApp app, TwkTonemapper* tm);
+/* ≙ the file name Application::screenshot builds (Application.cpp:2235-2239, getDateTime :1927-2010):
+ * <prefixScreenshot>_<spp>spp_<YYYMMDD_HHMMSS_mmm>.png|.hdr (tm_year and tm_mon as the reference prints them). */
+int twk_app_screenshot_path(TwkApp app, int tonemap, char* out, size_t capacity);
+
+/* Image files written by Application::screenshot through DevIL (Application.cpp:2251-2320), without DevIL:
+ * 8-bit RGB PNG (stored deflate blocks) and Radiance RGBE .hdr (flat scanlines). `bottomUp` != 0: row 0 of the
+ * buffer is the BOTTOM row of the picture (the renderer's convention, IL_ORIGIN_LOWER_LEFT). */
+int twk_write_png_rgb8(const char* path, int width, int height, const unsigned char* rgb8, int bottomUp);
+int twk_write_hdr_rgba32f(const char* path, int width, int height, const float* rgba, int bottomUp);
 
 /* Stand-alone host helpers (≙ sg::Triangles::create*, Camera::getFrustum, calculateTileShift). */
 int twk_mesh_plane(unsigned int tessU, unsigned int tessV, unsigned int upAxis, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx);

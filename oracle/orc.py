@@ -177,6 +177,18 @@ def oracle_math(op, x, y=None, libm=False):
     return out
 
 
+def oracle_tonemap(rgba, tonemapper=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0), libm=False):
+    """Application.cpp:2259-2297 on the CPU. tonemapper = gamma, whitePoint, colorBalance r g b, burnHighlights,
+    crushBlacks, saturation, brightness (TonemapperGUI field order). rgba float32 [..., 4] → uint8 [..., 3]."""
+    lib = _load(ORACLE_LIBM_PATH if libm else ORACLE_PATH)
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    tm = np.asarray(tonemapper, dtype=np.float32)
+    assert tm.size == 9 and a.shape[-1] == 4
+    out = np.empty(a.shape[:-1] + (3,), dtype=np.uint8)
+    assert lib.orc_tonemap(_f(tm), _f(a.reshape(-1)), C.c_size_t(a.size // 4), out.ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
+    return out
+
+
 class _Unit:
     """Scalar/vector unit taps shared by liboracle.so (orc_*) and libref_host.so (ref_*)."""
 

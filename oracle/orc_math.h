@@ -30,6 +30,8 @@ static inline float pm_expf(float x) { return ::expf(x); }
 static inline float pm_atanf(float x) { return ::atanf(x); }
 static inline float pm_atan2f(float y, float x) { return ::atan2f(y, x); }
 static inline float pm_acosf(float x) { return ::acosf(x); }
+static inline float pm_logf(float x) { return ::logf(x); }
+static inline float pm_powf(float x, float y) { return ::powf(x, y); }
 #else
 
 // Cephes sinf/cosf: octant reduction with a 3-part pi/4, degree-7/8 minimax polynomials.
@@ -152,6 +154,46 @@ static inline float pm_acosf(float x)
   if (x < -0.5f) return 3.14159265358979323846f - 2.0f * pm_asinf(sqrtf(0.5f * (1.0f + x)));
   if (x > 0.5f)  return 2.0f * pm_asinf(sqrtf(0.5f * (1.0f - x)));
   return 1.5707963267948966192f - pm_asinf(x);
+}
+// Cephes logf (tonemapper, Application.cpp:2283-2287): frexp split, mantissa folded to [sqrt(1/2), sqrt(2)),
+// polynomial of degree 9; subnormal arguments are treated as zero.
+static inline float pm_logf(float xx)
+{
+  if (xx < 0.0f) return bits2f(0x7fc00000u);
+  if (xx < 1.17549435e-38f) return bits2f(0xff800000u);
+  if (xx > 3.40282347e+38f) return xx;
+  const uint32_t u = f2bits(xx);
+  int e = (int) (u >> 23) - 126;
+  float x = bits2f((u & 0x007fffffu) | 0x3f000000u); // [0.5, 1)
+  if (x < 0.707106781186547524f) { e = e - 1; x = x + x - 1.0f; }
+  else { x = x - 1.0f; }
+  const float z = x * x;
+  float y = 7.0376836292e-2f;
+  y = y * x - 1.1514610310e-1f;
+  y = y * x + 1.1676998740e-1f;
+  y = y * x - 1.2420140846e-1f;
+  y = y * x + 1.4249322787e-1f;
+  y = y * x - 1.6668057665e-1f;
+  y = y * x + 2.0000714765e-1f;
+  y = y * x - 2.4999993993e-1f;
+  y = y * x + 3.3333331174e-1f;
+  y = y * x * z;
+  const float fe = (float) e;
+  y = y + -2.12194440e-4f * fe;
+  y = y + -0.5f * z;
+  float r = x + y;
+  r = r + 0.693359375f * fe;
+  return r;
+}
+
+// pow restricted to what the tonemapper needs (bases >= 0): exp(y log x), 0^y = 0 for y > 0, x^0 = 1.
+static inline float pm_powf(float x, float y)
+{
+  if (y == 0.0f) return 1.0f;
+  if (y == 1.0f) return x; // exact like libm's powf: neutral tonemapper settings leave the colour unchanged
+  if (x == 0.0f) return (y > 0.0f) ? 0.0f : bits2f(0x7f800000u);
+  if (!(x > 0.0f)) return bits2f(0x7fc00000u);
+  return pm_expf(y * pm_logf(x));
 }
 #endif // ORC_USE_LIBM
 

@@ -731,8 +731,57 @@ int orc_trace_rays(OrcHandle o, const float* rays, size_t numRays, int anyHit, f
   return 0;
 }
 
+// ---- tonemapper ------------------------------------------------------------------------------
+// Application::screenshot, tonemap branch (Application.cpp:2259-2297): the per-pixel loop, float3 helpers written out
+// (operator*, operator/ component-wise vector_math.h:509-529, lerp :547-550, clamp :148-151, powf :626-629).
+// tm = gamma, whitePoint, colorBalance[3], burnHighlights, crushBlacks, saturation, brightness (TonemapperGUI.h:34-43).
+int orc_tonemap(const float* tm, const float* rgba, size_t numPixels, unsigned char* rgb8)
+{
+  const float gamma = tm[0], whitePoint = tm[1];
+  const float balance[3] = {tm[2], tm[3], tm[4]};
+  const float invGamma       = 1.0f / gamma;                 // :2262
+  const float invWhitePoint  = tm[8] / whitePoint;           // :2264 brightness / whitePoint
+  const float burnHighlights = tm[5];
+  const float crushBlacks    = tm[6] + tm[6] + 1.0f;         // :2266
+  const float saturation     = tm[7];
+  for (size_t i = 0; i < numPixels; ++i)
+  {
+    float c[3];
+    for (int k = 0; k < 3; ++k)
+    {
+      float v = (invWhitePoint * balance[k]) * rgba[4 * i + k];           // :2275
+      v = v * ((v * burnHighlights + 1.0f) / (v + 1.0f));                 // :2276
+      c[k] = v;
+    }
+    float luminance = c[0] * 0.3f + c[1] * 0.59f + c[2] * 0.11f;         // :2278 dot()
+    for (int k = 0; k < 3; ++k)
+    {
+      c[k] = luminance + saturation * (c[k] - luminance);                 // :2279 lerp(make_float3(luminance), ldrColor, saturation)
+      c[k] = fmaxf(0.0f, c[k]);                                           // :2280
+    }
+    luminance = c[0] * 0.3f + c[1] * 0.59f + c[2] * 0.11f;               // :2282
+    if (luminance < 1.0f)
+    {
+      const float s = sqrtf(luminance);
+      for (int k = 0; k < 3; ++k)
+      {
+        const float crushed = pm_powf(c[k], crushBlacks);                 // :2285
+        c[k] = crushed + s * (c[k] - crushed);                            // :2286 lerp(crushed, ldrColor, sqrtf(luminance))
+        c[k] = fmaxf(0.0f, c[k]);                                         // :2287
+      }
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+      const float g = pm_powf(c[k], invGamma);
+      const float ldr = fmaxf(0.0f, fminf(g, 1.0f));                      // :2289 clamp()
+      rgb8[3 * i + k] = (unsigned char) (ldr * 255.0f);                   // :2291-2293
+    }
+  }
+  return 0;
+}
+
 // ---- unit taps for known-answer tests -------------------------------------------------------
-// op 0 sin, 1 cos, 2 exp, 3 atan2(x, y), 4 acos, 5 atan, 6 sqrt, 7 1/x
+// op 0 sin, 1 cos, 2 exp, 3 atan2(x, y), 4 acos, 5 atan, 6 sqrt, 7 1/x, 8 log, 9 pow(x, y)
 int orc_math(int op, const float* x, const float* y, float* out, size_t n)
 {
   for (size_t i = 0; i < n; ++i)
@@ -747,6 +796,8 @@ int orc_math(int op, const float* x, const float* y, float* out, size_t n)
       case 5: out[i] = pm_atanf(x[i]); break;
       case 6: out[i] = sqrtf(x[i]); break;
       case 7: out[i] = 1.0f / x[i]; break;
+      case 8: out[i] = pm_logf(x[i]); break;
+      case 9: out[i] = pm_powf(x[i], y[i]); break;
       default: return 1;
     }
   }

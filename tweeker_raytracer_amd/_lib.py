@@ -52,6 +52,17 @@ class DeviceState(C.Structure):
                 ("envRotation", C.c_float), ("clockFactor", C.c_float)]
 
 
+class Tonemapper(C.Structure):
+    """≙ TonemapperGUI (inc/TonemapperGUI.h:34-43); neutral defaults of Application.cpp:111-120."""
+    _fields_ = [("gamma", C.c_float), ("whitePoint", C.c_float), ("colorBalance", C.c_float * 3),
+                ("burnHighlights", C.c_float), ("crushBlacks", C.c_float), ("saturation", C.c_float),
+                ("brightness", C.c_float)]
+
+    def __init__(self, gamma=1.0, whitePoint=1.0, colorBalance=(1.0, 1.0, 1.0), burnHighlights=1.0, crushBlacks=0.0,
+                 saturation=1.0, brightness=1.0):
+        super().__init__(gamma, whitePoint, (C.c_float * 3)(*colorBalance), burnHighlights, crushBlacks, saturation, brightness)
+
+
 class LaunchStats(C.Structure):
     _fields_ = [("radianceRays", C.c_uint64), ("shadowRays", C.c_uint64), ("nodesVisited", C.c_uint64),
                 ("trianglesTested", C.c_uint64), ("instancesEntered", C.c_uint64), ("shadedHits", C.c_uint64),
@@ -76,12 +87,13 @@ SYMBOLS = [
     "twk_set_state", "twk_init_cameras", "twk_init_lights", "twk_init_materials", "twk_update_camera",
     "twk_update_light", "twk_update_material", "twk_init_texture", "twk_add_geometry", "twk_add_instance",
     "twk_build", "twk_clear_scene", "twk_launch", "twk_sync", "twk_set_launch_batch", "twk_get_launch_width", "twk_read_output",
-    "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_compositor", "twk_profile_enable",
+    "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_compositor", "twk_tonemap", "twk_profile_enable",
     "twk_profile_reset", "twk_profile_get", "twk_stats_enable", "twk_stats_get", "twk_stream_peak_gbps",
     "twk_debug_capture", "twk_debug_read_first_hits", "twk_trace_rays", "twk_debug_math",
     "twk_app_create", "twk_app_create_from_strings", "twk_app_destroy", "twk_app_info", "twk_app_set_resolution",
     "twk_app_get_state", "twk_app_get_cameras", "twk_app_get_lights", "twk_app_get_materials",
     "twk_app_get_geometry_sizes", "twk_app_get_geometry", "twk_app_get_instance", "twk_app_init_device",
+    "twk_app_get_tonemapper", "twk_app_screenshot_path", "twk_write_png_rgb8", "twk_write_hdr_rgba32f",
     "twk_mesh_plane", "twk_mesh_box", "twk_mesh_sphere", "twk_mesh_torus", "twk_mesh_parallelogram",
     "twk_camera_frustum", "twk_tile_column", "twk_launch_width", "twk_parse_tokens",
 ]

@@ -4,6 +4,7 @@ loadSceneDescription :1397-1878). Parsing, mesh generation and flattening run in
 libtweeker_hip.so; this class only exposes the result.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -83,6 +84,19 @@ class Application:
     def instances(self):
         return [self.instance(i) for i in range(self.info.numInstances)]
 
+    @property
+    def tonemapper(self):
+        """Tonemapper settings of the system description (Application.cpp:1244-1292)."""
+        tm = L.Tonemapper()
+        L.check(L.lib.twk_app_get_tonemapper(self._h, C.byref(tm)))
+        return tm
+
+    def screenshotPath(self, tonemap=True):
+        """≙ the file name of Application::screenshot: <prefix>_<spp>spp_<date>_<time>_000.png|.hdr."""
+        buf = C.create_string_buffer(4096)
+        L.check(L.lib.twk_app_screenshot_path(self._h, int(bool(tonemap)), buf, C.c_size_t(len(buf))))
+        return buf.value.decode()
+
     def initDevice(self, device, distribution=None):
         """≙ Application.cpp:303,328-332: initState, initCameras, initLights, initMaterials, initScene."""
         L.check(L.lib.twk_app_init_device(self._h, device.handle))
@@ -92,6 +106,18 @@ class Application:
             device.setState(st)
         else:
             device.state = st
+
+
+def write_png(path, rgb8, bottomUp=True):
+    """8-bit RGB PNG as Application::screenshot(true) stores it; rgb8 uint8 [H, W, 3]."""
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    L.check(L.lib.twk_write_png_rgb8(os.fsencode(path), int(a.shape[1]), int(a.shape[0]), a.ctypes.data_as(C.POINTER(C.c_ubyte)), int(bool(bottomUp))))
+
+
+def write_hdr(path, rgba, bottomUp=True):
+    """Radiance .hdr as Application::screenshot(false) stores it; rgba float32 [H, W, 4]."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    L.check(L.lib.twk_write_hdr_rgba32f(os.fsencode(path), int(a.shape[1]), int(a.shape[0]), a.ctypes.data_as(C.POINTER(C.c_float)), int(bool(bottomUp))))
 
 
 def _mesh_call(fn, *args):

@@ -32,6 +32,7 @@ void launchCompositor(const float4* tiles, float4* output, int width, int height
                       int tileSizeX, int tileShiftX, int tileShiftY, hipStream_t stream);
 void launchMathTap(int op, const float* x, const float* y, float* out, size_t n, hipStream_t stream);
 void launchStreamCopy(const float4* src, float4* dst, size_t n, hipStream_t stream);
+void launchTonemap(const float4* hdr, unsigned char* ldr, size_t numPixels, const TwkTonemapper& tm, hipStream_t stream);
 }
 
 using namespace twk;
@@ -856,6 +857,28 @@ int twk_compositor(TwkDevice dev, const void* tiles, void* output)
   return TWK_SUCCESS;
 }
 
+int twk_tonemap(TwkDevice dev, const TwkTonemapper* tm, const void* rgbaDevice, size_t numPixels, unsigned char* rgb8Host)
+{
+  int rc = activate(dev, "twk_tonemap"); if (rc) return rc;
+  if (!tm || !rgb8Host) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_tonemap: NULL argument");
+  if (!(tm->gamma > 0.0f) || !(tm->whitePoint > 0.0f)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_tonemap: gamma and whitePoint must be positive");
+  const float4* src = static_cast<const float4*>(rgbaDevice);
+  if (!src)
+  {
+    src = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
+    if (!src || !dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_tonemap: nothing has been rendered");
+    if (numPixels != (size_t) dev->launchWidth * dev->state.resolution[1]) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_tonemap: numPixels must be launchWidth*height for the handle's own buffer");
+  }
+  if (numPixels == 0) return TWK_SUCCESS;
+  ScopedDeviceBuffer<unsigned char> ldr;
+  HIP_TRY(ldr.allocate(numPixels * 3));
+  launchTonemap(src, ldr.ptr, numPixels, *tm, dev->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb8Host, ldr.ptr, numPixels * 3, hipMemcpyDeviceToHost, dev->stream));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  return TWK_SUCCESS;
+}
+
 // ---- measurement ------------------------------------------------------------------------------
 int twk_profile_enable(TwkDevice dev, int enable)
 {
@@ -986,7 +1009,7 @@ int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit,
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n)
 {
   int rc = activate(dev, "twk_debug_math"); if (rc) return rc;
-  if (op < 0 || op > 7 || !x || !out || (op == 3 && !y)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_math: bad arguments");
+  if (op < 0 || op > 9 || !x || !out || ((op == 3 || op == 9) && !y)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_math: bad arguments");
   if (n == 0) return TWK_SUCCESS;
   ScopedDeviceBuffer<float> dx, dy, dout;
   HIP_TRY(dx.allocate(n));

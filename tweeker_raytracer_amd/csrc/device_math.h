@@ -85,6 +85,40 @@ TWK_HD float expP(float x)
   return p * asFloat((uint32_t) (n + 127) << 23);
 }
 
+// --- log / pow (tonemapper only: Application.cpp:2283-2287 calls powf) -----------------------
+// Cephes logf: x = m 2^e with m in [sqrt(1/2), sqrt(2)), degree-9 polynomial in m - 1. Arguments below the normal
+// range count as zero (-inf), negative ones give NaN.
+TWK_HD float logP(float x)
+{
+  if (x < 0.0f) return asFloat(0x7fc00000u);
+  if (x < 1.17549435e-38f) return asFloat(0xff800000u);
+  if (x > 3.40282347e+38f) return x; // +inf
+  const uint32_t bits = asUint(x);
+  int e = (int) (bits >> 23) - 126;                         // frexp: x = m 2^e, m in [0.5, 1)
+  float m = asFloat((bits & 0x007fffffu) | 0x3f000000u);
+  if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+  else                           { m = m - 1.0f; }
+  const float z = m * m;
+  float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+              + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+              + 3.3333331174e-1f) * m * z;
+  const float fe = (float) e;
+  y = y + -2.12194440e-4f * fe;
+  y = y + -0.5f * z;
+  float r = m + y;
+  r = r + 0.693359375f * fe;
+  return r;
+}
+
+// pow for the tonemapper's non-negative bases: exp(y log x); 0^y = 0 for y > 0, x^0 = 1.
+TWK_HD float powP(float x, float y)
+{
+  if (y == 0.0f) return 1.0f;
+  if (y == 1.0f) return x; // exact, as libm: the neutral tonemapper (gamma 1, crushBlacks 0) is the identity
+  if (!(x > 0.0f)) return (x == 0.0f && y > 0.0f) ? 0.0f : ((x == 0.0f) ? asFloat(0x7f800000u) : asFloat(0x7fc00000u));
+  return expP(y * logP(x));
+}
+
 // --- atan / atan2 ----------------------------------------------------------------------------
 TWK_HD float atanP(float xx)
 {

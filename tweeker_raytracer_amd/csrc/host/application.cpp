@@ -97,12 +97,17 @@ bool Application::loadSystemDescription(const std::string& text, std::string& er
       if (ok) { camera.phi = f[0]; camera.theta = f[1]; camera.fov = f[2]; camera.distance = f[3]; }
     }
     else if (key == "prefixScreenshot") { ok = (parser.restOfLine(prefixScreenshot) == TOKEN_ID); }
-    else if (key == "gamma" || key == "whitePoint" || key == "burnHighlights" || key == "crushBlacks" ||
-             key == "saturation" || key == "brightness")
+    // tonemapper settings (Application.cpp:1244-1292), consumed by twk_tonemap / screenshot
+    else if (key == "gamma")          { ok = readFloat(parser, tonemapper.gamma); }
+    else if (key == "whitePoint")     { ok = readFloat(parser, tonemapper.whitePoint); }
+    else if (key == "burnHighlights") { ok = readFloat(parser, tonemapper.burnHighlights); }
+    else if (key == "crushBlacks")    { ok = readFloat(parser, tonemapper.crushBlacks); }
+    else if (key == "saturation")     { ok = readFloat(parser, tonemapper.saturation); }
+    else if (key == "brightness")     { ok = readFloat(parser, tonemapper.brightness); }
+    else if (key == "colorBalance")
     {
-      ok = readFloat(parser, f[0]); // tonemapper settings: display side, not part of the hot path
+      ok = readFloat(parser, tonemapper.colorBalance[0]) && readFloat(parser, tonemapper.colorBalance[1]) && readFloat(parser, tonemapper.colorBalance[2]);
     }
-    else if (key == "colorBalance") { ok = readFloat(parser, f[0]) && readFloat(parser, f[1]) && readFloat(parser, f[2]); }
     else
     {
       warnings.push_back("unknown system option name: " + key);
@@ -129,7 +134,7 @@ TwkDeviceState Application::deviceState() const
   s.resolution[0] = resolution[0];   s.resolution[1] = resolution[1];
   s.tileSize[0] = tileSize[0];       s.tileSize[1] = tileSize[1];
   s.pathLengths[0] = pathLengths[0]; s.pathLengths[1] = pathLengths[1];
-  s.distribution  = 0;
+  s.distribution  = (strategy == 0) ? 0 : 1; // full frames on one device, tiled across devices otherwise (Application.cpp:223-245)
   s.samplesSqrt   = samplesSqrt;
   s.lensShader    = lensShader;
   s.epsilonFactor = epsilonFactor;

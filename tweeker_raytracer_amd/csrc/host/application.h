@@ -87,6 +87,7 @@ public:
   float clockFactor   = 1000.0f;
   std::string environment;
   std::string prefixScreenshot = "./img";
+  TwkTonemapper tonemapper = {1.0f, 1.0f, {1.0f, 1.0f, 1.0f}, 1.0f, 0.0f, 1.0f, 1.0f}; // neutral (Application.cpp:111-120)
   OrbitCamera camera;
 
   std::vector<TwkCameraDefinition> cameras;

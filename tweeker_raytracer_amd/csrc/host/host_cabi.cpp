@@ -2,9 +2,11 @@
 // twk_camera_frustum, twk_tile_column, twk_launch_width). Pure host code: usable without a GPU.
 #include "application.h"
 #include "description_parser.h"
+#include "image_files.h"
 #include "../error_state.h"
 
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <sstream>
 
@@ -163,6 +165,59 @@ int twk_app_init_device(TwkApp app, TwkDevice dev)
     if ((rc = twk_add_instance(dev, fi.geometry, fi.transform, fi.material, fi.light, nullptr))) return rc;
   }
   return twk_build(dev);
+}
+
+int twk_app_get_tonemapper(TwkApp app, TwkTonemapper* tm)
+{
+  if (!app || !tm) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_tonemapper: NULL argument");
+  *tm = app->app.tonemapper;
+  return TWK_SUCCESS;
+}
+
+// ≙ Application::screenshot's path (Application.cpp:2235-2239,2256,2303) with getDateTime's Linux branch (:1927-2008),
+// which prints tm_year (years since 1900) and tm_mon (0-based) as they are and "000" for the milliseconds.
+int twk_app_screenshot_path(TwkApp app, int tonemap, char* out, size_t capacity)
+{
+  if (!app || !out) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_screenshot_path: NULL argument");
+  time_t rawtime;
+  time(&rawtime);
+  struct tm ts;
+  localtime_r(&rawtime, &ts);
+  std::ostringstream path;
+  const int spp = app->app.samplesSqrt * app->app.samplesSqrt;
+  path << app->app.prefixScreenshot << "_" << spp << "spp_";
+  path << ts.tm_year;
+  if (ts.tm_mon < 10) path << '0';
+  path << ts.tm_mon;
+  if (ts.tm_mday < 10) path << '0';
+  path << ts.tm_mday << '_';
+  if (ts.tm_hour < 10) path << '0';
+  path << ts.tm_hour;
+  if (ts.tm_min < 10) path << '0';
+  path << ts.tm_min;
+  if (ts.tm_sec < 10) path << '0';
+  path << ts.tm_sec << '_' << "000";
+  path << (tonemap ? ".png" : ".hdr");
+  const std::string s = path.str();
+  if (s.size() + 1 > capacity) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_screenshot_path: buffer too small");
+  memcpy(out, s.c_str(), s.size() + 1);
+  return TWK_SUCCESS;
+}
+
+int twk_write_png_rgb8(const char* path, int width, int height, const unsigned char* rgb8, int bottomUp)
+{
+  if (!path || !rgb8 || width <= 0 || height <= 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_write_png_rgb8: bad arguments");
+  std::string error;
+  if (!writePngRgb8(path, width, height, rgb8, bottomUp != 0, error)) return twkSetError(TWK_ERROR_IO, error);
+  return TWK_SUCCESS;
+}
+
+int twk_write_hdr_rgba32f(const char* path, int width, int height, const float* rgba, int bottomUp)
+{
+  if (!path || !rgba || width <= 0 || height <= 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_write_hdr_rgba32f: bad arguments");
+  std::string error;
+  if (!writeHdrRgba32f(path, width, height, rgba, bottomUp != 0, error)) return twkSetError(TWK_ERROR_IO, error);
+  return TWK_SUCCESS;
 }
 
 int twk_mesh_plane(unsigned int tessU, unsigned int tessV, unsigned int upAxis, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx)

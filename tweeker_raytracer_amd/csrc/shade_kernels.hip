@@ -10,6 +10,7 @@
 // Per-path RNG draw order is the reference's: jitter rng2; per bounce the BSDF's draws, then NEE rng2
 // [+ rng when more than one light], then Russian roulette rng.
 #include "shade_device.h"
+#include "../../include/tweeker_hip.h"
 
 namespace twk {
 // One thread per path = (sample, launch index): seed, jitter, lens shader, path state reset, primary ray into
@@ -254,8 +255,46 @@ __global__ void mathTapKernel(int op, const float* __restrict__ x, const float* 
       case 5: r = atanP(x[i]); break;
       case 6: r = sqrtf(x[i]); break;
       case 7: r = 1.0f / x[i]; break;
+      case 8: r = logP(x[i]); break;
+      case 9: r = powP(x[i], y[i]); break;
     }
     out[i] = r;
+  }
+}
+
+// Tonemapper of Application::screenshot (Application.cpp:2259-2297, the loop its authors mark "PERF Add a native CUDA
+// kernel doing this"; same operator as the GLSL display shader Rasterizer.cpp:553-578): white point, colour balance,
+// burn highlights, saturation, crush blacks, gamma, then truncation to 8 bits. One pixel's three bytes per thread
+// iteration; pow is device_math.h powP (fixed algorithm, the oracle evaluates the same).
+struct TonemapConstants { float invGamma, invWhitePoint, burnHighlights, crushBlacks, saturation; float colorBalance[3]; };
+
+TWK_D V3 pow3(const V3& v, float e) { return v3(powP(v.x, e), powP(v.y, e), powP(v.z, e)); }
+TWK_D V3 max3(const V3& v, float lo) { return v3(fmaxf(lo, v.x), fmaxf(lo, v.y), fmaxf(lo, v.z)); }
+TWK_D float saturateP(float v) { return fmaxf(0.0f, fminf(v, 1.0f)); } // clamp(), vector_math.h:148-151
+
+__global__ void tonemapKernel(const float4* __restrict__ hdr, unsigned char* __restrict__ ldr, size_t numPixels, TonemapConstants c)
+{
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < numPixels; i += (size_t) gridDim.x * blockDim.x)
+  {
+    const V3 hdrColor = v3(hdr[i]);
+    V3 ldrColor = v3(c.invWhitePoint * c.colorBalance[0], c.invWhitePoint * c.colorBalance[1], c.invWhitePoint * c.colorBalance[2]) * hdrColor; // :2275
+    ldrColor = ldrColor * v3((ldrColor.x * c.burnHighlights + 1.0f) / (ldrColor.x + 1.0f),
+                             (ldrColor.y * c.burnHighlights + 1.0f) / (ldrColor.y + 1.0f),
+                             (ldrColor.z * c.burnHighlights + 1.0f) / (ldrColor.z + 1.0f));                                             // :2276
+    float luminance = dot(ldrColor, v3(0.3f, 0.59f, 0.11f));
+    ldrColor = lerp(v3(luminance), ldrColor, c.saturation);
+    ldrColor = max3(ldrColor, 0.0f);
+    luminance = dot(ldrColor, v3(0.3f, 0.59f, 0.11f));
+    if (luminance < 1.0f)
+    {
+      const V3 crushed = pow3(ldrColor, c.crushBlacks);
+      ldrColor = lerp(crushed, ldrColor, sqrtf(luminance));
+      ldrColor = max3(ldrColor, 0.0f);
+    }
+    ldrColor = pow3(ldrColor, c.invGamma);
+    ldr[3 * i + 0] = (unsigned char) (saturateP(ldrColor.x) * 255.0f);
+    ldr[3 * i + 1] = (unsigned char) (saturateP(ldrColor.y) * 255.0f);
+    ldr[3 * i + 2] = (unsigned char) (saturateP(ldrColor.z) * 255.0f);
   }
 }
 
@@ -285,6 +324,17 @@ void launchCompositor(const float4* tiles, float4* output, int width, int height
 void launchMathTap(int op, const float* x, const float* y, float* out, size_t n, hipStream_t stream)
 {
   hipLaunchKernelGGL(mathTapKernel, dim3(1024), dim3(256), 0, stream, op, x, y, out, n);
+}
+void launchTonemap(const float4* hdr, unsigned char* ldr, size_t numPixels, const TwkTonemapper& tm, hipStream_t stream)
+{
+  TonemapConstants c;
+  c.invGamma       = 1.0f / tm.gamma;
+  c.invWhitePoint  = tm.brightness / tm.whitePoint;
+  c.burnHighlights = tm.burnHighlights;
+  c.crushBlacks    = tm.crushBlacks + tm.crushBlacks + 1.0f;
+  c.saturation     = tm.saturation;
+  c.colorBalance[0] = tm.colorBalance[0]; c.colorBalance[1] = tm.colorBalance[1]; c.colorBalance[2] = tm.colorBalance[2];
+  hipLaunchKernelGGL(tonemapKernel, dim3(2048), dim3(256), 0, stream, hdr, ldr, numPixels, c);
 }
 void launchStreamCopy(const float4* src, float4* dst, size_t n, hipStream_t stream)
 {

@@ -157,6 +157,21 @@ class Device:
         L.check(L.lib.twk_profile_get(self._h, ms, n))
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(KERNEL_CLASSES)}
 
+    def tonemap(self, tonemapper=None, rgbaDevicePointer=None, shape=None):
+        """RGBA32F → RGB8 with the reference's tonemapper (Application.cpp:2259-2297) on the device. Without a pointer
+        the handle's own accumulation buffer (launchWidth x height) is converted; returns uint8 [H, W, 3], row 0 at the
+        bottom like the float buffer."""
+        tm = tonemapper if tonemapper is not None else L.Tonemapper()
+        if rgbaDevicePointer is None:
+            h, w = self.state.resolution[1], self.launchWidth
+            ptr = None
+        else:
+            h, w = shape
+            ptr = C.c_void_p(int(rgbaDevicePointer))
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        L.check(L.lib.twk_tonemap(self._h, C.byref(tm), ptr, C.c_size_t(h * w), out.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return out
+
     def statsEnable(self, enable=True):
         L.check(L.lib.twk_stats_enable(self._h, int(bool(enable))))
 
