@@ -69,15 +69,15 @@ def test_tonemap_kernel_matches_oracle(twk, orc):
     dev.close()
 
 
-def _run_cli(tmp_path, strategy, env=None):
+def _run_cli(tmp_path, strategy, env=None, base="system_rtigo3_cornell_box.txt", scene="scene_rtigo3_cornell_box.txt", extra=""):
     system = tmp_path / f"system_{strategy}.txt"
-    text = open(scene_path("system_rtigo3_cornell_box.txt")).read()
+    text = open(scene_path(base)).read()
     text = re.sub(r"(?m)^resolution .*$", "resolution 96 64", text)
     text = re.sub(r"(?m)^samplesSqrt .*$", "samplesSqrt 2", text)
     text = re.sub(r"(?m)^strategy .*$", f"strategy {strategy}", text)
-    text += f"\nprefixScreenshot {tmp_path}/shot{strategy}\ngamma 2.2\ncolorBalance 1.0 0.95 0.9\nburnHighlights 0.8\ncrushBlacks 0.2\nsaturation 1.2\nbrightness 0.8\n"
+    text += f"\nprefixScreenshot {tmp_path}/shot{strategy}\ngamma 2.2\ncolorBalance 1.0 0.95 0.9\nburnHighlights 0.8\ncrushBlacks 0.2\nsaturation 1.2\nbrightness 0.8\n" + extra
     system.write_text(text)
-    r = subprocess.run([CLI, "-s", str(system), "-d", scene_path("scene_rtigo3_cornell_box.txt"), "-m", "1"],
+    r = subprocess.run([CLI, "-s", str(system), "-d", scene_path(scene), "-m", "1"], cwd=str(tmp_path),
                        capture_output=True, text=True, timeout=300, env={**os.environ, **(env or {})})
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
@@ -99,3 +99,32 @@ def test_command_line_benchmark_and_screenshot(twk, orc, tmp_path):
     # strategy 1: three handles share this GPU, tiles → peer copies → one compositor launch → same picture
     _, png3 = _run_cli(tmp_path, 1, env={"TWK_CLI_VIRTUAL_DEVICES": "3"})
     assert np.array_equal(png3, expect), f"{(png3 != expect).any(-1).sum()} of {png3.shape[0] * png3.shape[1]} pixels differ, columns {np.unique(np.nonzero((png3 != expect).any(-1))[1])[:40]}"
+
+
+def test_command_line_environment_map_from_file(twk, orc, tmp_path):
+    """C3's scene through the command line with the spherical environment read from picture files ("envMap", miss 2):
+    a PFM (exact floats) and a Radiance .hdr (RGBE), decoded by the library's own readers; the oracle gets the same
+    decoded texels. Exercises createPictures → initTextures → calculateSphericalCDF → miss / light programs."""
+    from procedural import environment_hdr
+    env = environment_hdr(128, 64)
+    (tmp_path / "sky.pfm").write_bytes(b"PF\n128 64\n-1.0\n" + env[..., :3].astype("<f4").tobytes())
+    twk.write_hdr(str(tmp_path / "sky.hdr"), env, bottomUp=True)
+    assert np.array_equal(twk.load_image(str(tmp_path / "sky.pfm")), env)
+    pictures = {}
+    for k, name in enumerate(("sky.pfm", "sky.hdr")):
+        system, png = _run_cli(tmp_path, 0, base="system_intro_07.txt", scene="scene_intro_07.txt", extra=f"envMap {tmp_path}/{name}\n")
+        app = twk.Application(system, scene_path("scene_intro_07.txt"))
+        assert app.environment.endswith(name) and app.info.miss == 2
+        ref = orc.Oracle(miss=2)
+        ref.initTexture(2, twk.load_image(app.environment))
+        ref.loadApplication(app)
+        for i in range(4):
+            ref.render(i)
+        assert np.array_equal(png, orc.oracle_tonemap(ref.getOutputBufferHost(), TM)[::-1]), name
+        pictures[name] = png
+    assert pictures["sky.pfm"].max() > 150 and not np.array_equal(pictures["sky.pfm"], pictures["sky.hdr"])  # RGBE quantisation is visible in the bytes
+    # without the file the run stops with the library's message instead of rendering a black sky
+    system = tmp_path / "system_missing.txt"
+    system.write_text(open(scene_path("system_intro_07.txt")).read() + f"\nresolution 32 32\nenvMap {tmp_path}/nothing.hdr\n")
+    r = subprocess.run([CLI, "-s", str(system), "-d", scene_path("scene_intro_07.txt"), "-m", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "not loaded" in r.stderr and "environment texture" in r.stderr

@@ -9,9 +9,9 @@ from ._lib import (TwkError, CameraDefinition, LightDefinition, MaterialGUI, Tri
                    LaunchStats, AppInfo, Tonemapper, LIB_PATH)
 from .device import Device, device_count
 from .application import Application, mesh_plane, mesh_box, mesh_sphere, mesh_torus, mesh_parallelogram, \
-    camera_frustum, tile_column, launch_width, parse_tokens, write_png, write_hdr
+    camera_frustum, tile_column, launch_width, parse_tokens, write_png, write_hdr, load_image
 
 __all__ = ["Device", "Application", "TwkError", "device_count", "CameraDefinition", "LightDefinition",
            "MaterialGUI", "TriangleAttributes", "DeviceState", "LaunchStats", "AppInfo", "LIB_PATH",
            "mesh_plane", "mesh_box", "mesh_sphere", "mesh_torus", "mesh_parallelogram", "camera_frustum",
-           "tile_column", "launch_width", "parse_tokens", "Tonemapper", "write_png", "write_hdr"]
+           "tile_column", "launch_width", "parse_tokens", "Tonemapper", "write_png", "write_hdr", "load_image"]

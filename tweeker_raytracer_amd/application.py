@@ -91,6 +91,13 @@ class Application:
         L.check(L.lib.twk_app_get_tonemapper(self._h, C.byref(tm)))
         return tm
 
+    @property
+    def environment(self):
+        """File name given with "envMap" in the system description (Application.cpp:1151-1156)."""
+        buf = C.create_string_buffer(4096)
+        L.check(L.lib.twk_app_get_environment(self._h, buf, C.c_size_t(len(buf))))
+        return buf.value.decode()
+
     def screenshotPath(self, tonemap=True):
         """≙ the file name of Application::screenshot: <prefix>_<spp>spp_<date>_<time>_000.png|.hdr."""
         buf = C.create_string_buffer(4096)
@@ -106,6 +113,15 @@ class Application:
             device.setState(st)
         else:
             device.state = st
+
+
+def load_image(path):
+    """≙ Picture::load + Texture::create* format expansion: PNG / Radiance .hdr / PFM → float32 [H, W, 4], row 0 = bottom."""
+    w, h = C.c_int(0), C.c_int(0)
+    L.check(L.lib.twk_load_image(os.fsencode(path), C.byref(w), C.byref(h), None, C.c_size_t(0)))
+    out = np.empty((h.value, w.value, 4), dtype=np.float32)
+    L.check(L.lib.twk_load_image(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(out.size)))
+    return out
 
 
 def write_png(path, rgb8, bottomUp=True):

@@ -9,6 +9,7 @@
 #include <ctime>
 #include <fstream>
 #include <sstream>
+#include <vector>
 
 using namespace twk;
 
@@ -200,6 +201,29 @@ int twk_app_screenshot_path(TwkApp app, int tonemap, char* out, size_t capacity)
   path << (tonemap ? ".png" : ".hdr");
   const std::string s = path.str();
   if (s.size() + 1 > capacity) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_screenshot_path: buffer too small");
+  memcpy(out, s.c_str(), s.size() + 1);
+  return TWK_SUCCESS;
+}
+
+int twk_load_image(const char* path, int* width, int* height, float* rgba, size_t capacityFloats)
+{
+  if (!path || !width || !height) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_load_image: NULL argument");
+  int w = 0, h = 0;
+  std::vector<float> pixels;
+  std::string error;
+  if (!loadImageRgba32f(path, w, h, pixels, error)) return twkSetError(TWK_ERROR_IO, "twk_load_image: " + error);
+  *width = w; *height = h;
+  if (!rgba) return TWK_SUCCESS;
+  if (capacityFloats < pixels.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_load_image: buffer smaller than width*height*4 floats");
+  memcpy(rgba, pixels.data(), pixels.size() * sizeof(float));
+  return TWK_SUCCESS;
+}
+
+int twk_app_get_environment(TwkApp app, char* out, size_t capacity)
+{
+  if (!app || !out || capacity == 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_environment: NULL argument");
+  const std::string& s = app->app.environment;
+  if (s.size() + 1 > capacity) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_environment: buffer too small");
   memcpy(out, s.c_str(), s.size() + 1);
   return TWK_SUCCESS;
 }

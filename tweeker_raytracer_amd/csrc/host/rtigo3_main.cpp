@@ -63,6 +63,28 @@ bool parseCommandLine(int argc, char* argv[], Options& o)
   return true;
 }
 
+// ≙ Application::createPictures (Application.cpp:679-699) + Raytracer::initTextures: the two hard-coded material
+// pictures and, for miss 2, the environment map named by "envMap". A picture that cannot be read is reported and
+// skipped (materials that ask for it then render untextured); JPEG is not decodable here, so the albedo picture is
+// also looked up as ./NVIDIA_Logo.png.
+struct PictureFile { int slot; std::vector<std::string> candidates; };
+
+bool loadPicture(const PictureFile& picture, int& width, int& height, std::vector<float>& rgba)
+{
+  for (const std::string& path : picture.candidates)
+  {
+    if (twk_load_image(path.c_str(), &width, &height, nullptr, 0) != TWK_SUCCESS) continue;
+    rgba.resize((size_t) width * height * 4);
+    if (twk_load_image(path.c_str(), &width, &height, rgba.data(), rgba.size()) == TWK_SUCCESS)
+    {
+      std::cerr << "INFO: picture " << path << " " << width << " x " << height << std::endl;
+      return true;
+    }
+  }
+  std::cerr << "WARNING: picture " << picture.candidates.front() << " not loaded: " << twk_last_error() << std::endl;
+  return false;
+}
+
 #define TWK_OK(call) do { if ((call) != TWK_SUCCESS) { std::cerr << "ERROR: " << #call << ": " << twk_last_error() << std::endl; return 1; } } while (0)
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::cerr << "ERROR: " << #call << ": " << hipGetErrorString(e_) << std::endl; return 1; } } while (0)
 
@@ -106,11 +128,20 @@ int main(int argc, char* argv[])
   std::vector<TwkDevice> devices((size_t) count, nullptr);
   TwkDeviceState state;
   TWK_OK(twk_app_get_state(app, &state));
-  for (int i = 0; i < count; ++i)
+  for (int i = 0; i < count; ++i) TWK_OK(twk_device_create(&devices[(size_t) i], ordinals[(size_t) i], i, count, info.miss));
+
+  std::vector<PictureFile> pictures = {{TWK_TEXTURE_ALBEDO, {"./NVIDIA_Logo.jpg", "./NVIDIA_Logo.png"}}, {TWK_TEXTURE_CUTOUT, {"./slots_alpha.png"}}};
+  char environment[4096];
+  TWK_OK(twk_app_get_environment(app, environment, sizeof(environment)));
+  if (info.miss == 2 && environment[0] != 0) pictures.push_back({TWK_TEXTURE_ENVIRONMENT, {environment}});
+  for (const PictureFile& picture : pictures)
   {
-    TWK_OK(twk_device_create(&devices[(size_t) i], ordinals[(size_t) i], i, count, info.miss));
-    TWK_OK(twk_app_init_device(app, devices[(size_t) i]));
+    int w = 0, h = 0;
+    std::vector<float> rgba;
+    if (!loadPicture(picture, w, h, rgba)) continue;
+    for (int i = 0; i < count; ++i) TWK_OK(twk_init_texture(devices[(size_t) i], picture.slot, rgba.data(), w, h));
   }
+  for (int i = 0; i < count; ++i) TWK_OK(twk_app_init_device(app, devices[(size_t) i]));
   std::cerr << "INFO: " << count << " device(s), " << info.resolution[0] << " x " << info.resolution[1] << ", "
             << info.samplesSqrt * info.samplesSqrt << " spp, " << info.numInstances << " instances" << std::endl;
 
