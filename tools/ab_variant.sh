@@ -9,5 +9,5 @@ cd "$(dirname "$0")/../tweeker_raytracer_amd/csrc"
 make -s > /dev/null
 mkdir -p ../../build
 hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function "$@" -c trace_kernels.hip -o ../../build/trace_$NAME.o 2>&1 | grep -E "error" || true
-hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/lib_$NAME.so device_api.o bvh_build.o ../../build/trace_$NAME.o shade_kernels.o tail_kernel.o host/description_parser.o host/triangle_meshes.o host/application.o host/host_cabi.o
+hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/lib_$NAME.so device_api.o bvh_build.o ../../build/trace_$NAME.o shade_kernels.o tail_kernel.o host/description_parser.o host/triangle_meshes.o host/application.o host/image_files.o host/host_cabi.o -lz
 ls -la ../../build/lib_$NAME.so

@@ -711,7 +711,7 @@ int twk_build(TwkDevice dev)
     HIP_TRY(hipMemcpyAsync(dev->d_indices + g.indexBase, g.indices.data(), sizeof(unsigned int) * g.indices.size(), hipMemcpyHostToDevice, dev->stream));
   }
 
-  if (const char* e = getenv("TWK_MAX_LEAF")) dev->builder.setMaxLeaf(atoi(e)); // tuning knob, default 4 triangles per leaf
+  if (const char* e = getenv("TWK_MAX_LEAF")) dev->builder.setMaxLeaf(atoi(e)); // tuning knob, default 2 triangles per leaf
   // bottom level: one LBVH per geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
   for (GeometryHost& g : dev->geometries)
   {
