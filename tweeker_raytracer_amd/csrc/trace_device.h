@@ -43,35 +43,54 @@ TWK_D bool slabTest(const TraceRay& r, float lox, float loy, float loz, float hi
   return tn * 0.9999975f <= tf * 1.0000025f;
 }
 
+// Woop-Benthin-Wald ray constants. The axis permutation (kx, ky, kz) is a cyclic shift of (x, y, z) chosen by the
+// dominant direction axis kz, with kx and ky exchanged when d[kz] < 0; it is kept as three lane flags and applied with
+// selects. (Indexing the components with integer kx / ky / kz — `k == 0 ? x : k == 1 ? y : z` — is turned into a
+// switch by the compiler and then into ~20 scalar exec-mask instructions and two branches PER COMPONENT: the triangle
+// test was 490 instructions long, most of them scalar.)
 struct WoopConstants
 {
-  int   kx, ky, kz;
+  bool  zIsX, zIsY, flip; // kz == 0, kz == 1, d[kz] < 0
   float Sx, Sy, Sz;
 };
 
-TWK_D float component(const V3& v, int k) { return (k == 0) ? v.x : ((k == 1) ? v.y : v.z); }
+// (v[kx], v[ky], v[kz]) of the permutation described by w.
+TWK_D void woopPermute(const WoopConstants& w, const V3& v, float& vx, float& vy, float& vz)
+{
+  const float c0 = w.zIsX ? v.y : (w.zIsY ? v.z : v.x);
+  const float c1 = w.zIsX ? v.z : (w.zIsY ? v.x : v.y);
+  vz             = w.zIsX ? v.x : (w.zIsY ? v.y : v.z);
+  vx = w.flip ? c1 : c0;
+  vy = w.flip ? c0 : c1;
+}
 
 TWK_D void woopSetup(const V3& d, WoopConstants& w)
 {
   const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-  int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
-  int kx = (kz == 2) ? 0 : kz + 1;
-  int ky = (kx == 2) ? 0 : kx + 1;
-  const float dz = component(d, kz);
-  if (dz < 0.0f) { const int s = kx; kx = ky; ky = s; }
-  w.kx = kx; w.ky = ky; w.kz = kz;
-  w.Sx = component(d, kx) / dz;
-  w.Sy = component(d, ky) / dz;
+  // kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2)
+  w.zIsX = (ax > ay) & (ax > az);
+  w.zIsY = !(ax > ay) & (ay > az);
+  w.flip = false;
+  float dx, dy, dz;
+  woopPermute(w, d, dx, dy, dz);
+  w.flip = dz < 0.0f; // swap kx and ky: keeps the winding of the sheared triangle
+  const float sx = w.flip ? dy : dx, sy = w.flip ? dx : dy;
+  w.Sx = sx / dz;
+  w.Sy = sy / dz;
   w.Sz = 1.0f / dz;
 }
 
+// Straight-line: every lane runs the whole test and the verdict is one flag (a wave leaves early only when all of its
+// lanes fail, which with ~20 active lanes practically never happens, while each early return costs exec-mask
+// bookkeeping for everyone). The arithmetic of an accepted hit is unchanged.
 TWK_D bool woopIntersect(const WoopConstants& w, const V3& o, const V3& p0, const V3& p1, const V3& p2,
                          float tmin, float& t, float& beta, float& gamma)
 {
   const V3 A = p0 - o, B = p1 - o, C = p2 - o;
-  const float Akx = component(A, w.kx), Aky = component(A, w.ky), Akz = component(A, w.kz);
-  const float Bkx = component(B, w.kx), Bky = component(B, w.ky), Bkz = component(B, w.kz);
-  const float Ckx = component(C, w.kx), Cky = component(C, w.ky), Ckz = component(C, w.kz);
+  float Akx, Aky, Akz, Bkx, Bky, Bkz, Ckx, Cky, Ckz;
+  woopPermute(w, A, Akx, Aky, Akz);
+  woopPermute(w, B, Bkx, Bky, Bkz);
+  woopPermute(w, C, Ckx, Cky, Ckz);
 
   const float Ax = Akx - w.Sx * Akz, Ay = Aky - w.Sy * Akz;
   const float Bx = Bkx - w.Sx * Bkz, By = Bky - w.Sy * Bkz;
@@ -81,7 +100,7 @@ TWK_D bool woopIntersect(const WoopConstants& w, const V3& o, const V3& p0, cons
   float V = Ax * Cy - Ay * Cx;
   float W = Bx * Ay - By * Ax;
 
-  if (U == 0.0f || V == 0.0f || W == 0.0f)
+  if ((U == 0.0f) | (V == 0.0f) | (W == 0.0f)) // rare: an edge function vanished in float, decide it in double
   {
     const double CxBy = (double) Cx * (double) By, CyBx = (double) Cy * (double) Bx;
     U = (float) (CxBy - CyBx);
@@ -91,21 +110,16 @@ TWK_D bool woopIntersect(const WoopConstants& w, const V3& o, const V3& p0, cons
     W = (float) (BxAy - ByAx);
   }
 
-  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
-
+  const bool mixedSigns = ((U < 0.0f) | (V < 0.0f) | (W < 0.0f)) & ((U > 0.0f) | (V > 0.0f) | (W > 0.0f));
   const float det = U + V + W;
-  if (det == 0.0f) return false;
-
   const float Az = w.Sz * Akz, Bz = w.Sz * Bkz, Cz = w.Sz * Ckz;
   const float T = U * Az + V * Bz + W * Cz;
   const float rcpDet = 1.0f / det;
   const float tt = T * rcpDet;
-  if (!(tt > tmin)) return false;
-
   t     = tt;
   beta  = V * rcpDet;
   gamma = W * rcpDet;
-  return true;
+  return !mixedSigns & (det != 0.0f) & (tt > tmin);
 }
 
 struct TraceResult

@@ -125,7 +125,7 @@ traceKernel(LaunchParams p, int depth)
   float tmin = 0.0f;
   TraceResult res; res.t = 0.0f; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
   TraceRay ray; ray.o = v3(0.0f); ray.d = v3(0.0f); ray.id = v3(0.0f);
-  WoopConstants woop; woop.kx = 0; woop.ky = 1; woop.kz = 2; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
+  WoopConstants woop; woop.zIsX = false; woop.zIsY = false; woop.flip = false; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
   unsigned int guard = 0;
   bool retrace = false; // LDS stack overflow: the ray is re-traced by traceOverflowKernel with the spilling traverse()
@@ -299,9 +299,9 @@ traceKernel(LaunchParams p, int depth)
           if (woopIntersect(woop, triOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
           {
             const int prim = __float_as_int(a.w);
-            const bool closer = (t < res.t) ||
-                                (t == res.t && res.instance >= 0 &&
-                                 (triInstance < res.instance || (triInstance == res.instance && prim < res.primitive)));
+            const bool closer = (t < res.t) |
+                                ((t == res.t) & (res.instance >= 0) &
+                                 ((triInstance < res.instance) | ((triInstance == res.instance) & (prim < res.primitive))));
             if (closer)
             {
               res.t = t; res.beta = beta; res.gamma = gamma; res.instance = triInstance; res.primitive = prim; res.triangleSlot = ts;
