@@ -44,18 +44,22 @@ TWK_D bool slabTest(const TraceRay& r, float lox, float loy, float loz, float hi
 }
 
 // Woop-Benthin-Wald ray constants. The axis permutation (kx, ky, kz) is a cyclic shift of (x, y, z) chosen by the
-// dominant direction axis kz, with kx and ky exchanged when d[kz] < 0; it is kept as three lane flags and applied with
-// selects. (Indexing the components with integer kx / ky / kz — `k == 0 ? x : k == 1 ? y : z` — is turned into a
+// dominant direction axis kz, with kx and ky exchanged when d[kz] < 0; it is kept as three flag bits in one register
+// (lane flags held as bools live in scalar masks and cost scalar merge instructions at the end of every divergent
+// region) and applied with selects. (Indexing the components with integer kx / ky / kz — `k == 0 ? x : k == 1 ? y : z` — is turned into a
 // switch by the compiler and then into ~20 scalar exec-mask instructions and two branches PER COMPONENT: the triangle
 // test was 490 instructions long, most of them scalar.)
 struct WoopConstants
 {
-  bool  zIsX, zIsY, flip; // kz == 0, kz == 1, d[kz] < 0
+  unsigned int perm; // bit 0: kz == 0, bit 1: kz == 1, bit 2: d[kz] < 0 (kx and ky exchanged)
   float Sx, Sy, Sz;
 };
 
+struct WoopPermutation { bool zIsX, zIsY, flip; };
+TWK_D WoopPermutation woopFlags(unsigned int perm) { WoopPermutation f; f.zIsX = (perm & 1u) != 0u; f.zIsY = (perm & 2u) != 0u; f.flip = (perm & 4u) != 0u; return f; }
+
 // (v[kx], v[ky], v[kz]) of the permutation described by w.
-TWK_D void woopPermute(const WoopConstants& w, const V3& v, float& vx, float& vy, float& vz)
+TWK_D void woopPermute(const WoopPermutation& w, const V3& v, float& vx, float& vy, float& vz)
 {
   const float c0 = w.zIsX ? v.y : (w.zIsY ? v.z : v.x);
   const float c1 = w.zIsX ? v.z : (w.zIsY ? v.x : v.y);
@@ -68,13 +72,15 @@ TWK_D void woopSetup(const V3& d, WoopConstants& w)
 {
   const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
   // kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2)
-  w.zIsX = (ax > ay) & (ax > az);
-  w.zIsY = !(ax > ay) & (ay > az);
-  w.flip = false;
+  WoopPermutation f;
+  f.zIsX = (ax > ay) & (ax > az);
+  f.zIsY = !(ax > ay) & (ay > az);
+  f.flip = false;
   float dx, dy, dz;
-  woopPermute(w, d, dx, dy, dz);
-  w.flip = dz < 0.0f; // swap kx and ky: keeps the winding of the sheared triangle
-  const float sx = w.flip ? dy : dx, sy = w.flip ? dx : dy;
+  woopPermute(f, d, dx, dy, dz);
+  f.flip = dz < 0.0f; // swap kx and ky: keeps the winding of the sheared triangle
+  w.perm = (f.zIsX ? 1u : 0u) | (f.zIsY ? 2u : 0u) | (f.flip ? 4u : 0u);
+  const float sx = f.flip ? dy : dx, sy = f.flip ? dx : dy;
   w.Sx = sx / dz;
   w.Sy = sy / dz;
   w.Sz = 1.0f / dz;
@@ -87,10 +93,11 @@ TWK_D bool woopIntersect(const WoopConstants& w, const V3& o, const V3& p0, cons
                          float tmin, float& t, float& beta, float& gamma)
 {
   const V3 A = p0 - o, B = p1 - o, C = p2 - o;
+  const WoopPermutation f = woopFlags(w.perm);
   float Akx, Aky, Akz, Bkx, Bky, Bkz, Ckx, Cky, Ckz;
-  woopPermute(w, A, Akx, Aky, Akz);
-  woopPermute(w, B, Bkx, Bky, Bkz);
-  woopPermute(w, C, Ckx, Cky, Ckz);
+  woopPermute(f, A, Akx, Aky, Akz);
+  woopPermute(f, B, Bkx, Bky, Bkz);
+  woopPermute(f, C, Ckx, Cky, Ckz);
 
   const float Ax = Akx - w.Sx * Akz, Ay = Aky - w.Sy * Akz;
   const float Bx = Bkx - w.Sx * Bkz, By = Bky - w.Sy * Bkz;

@@ -118,24 +118,33 @@ traceKernel(LaunchParams p, int depth)
   bool exhausted = false;
 
   // per-lane ray state
-  bool hasRay = false, anyHit = false, done = false; // done: the lane's ray completed and its result is not yet written
-  bool isShadow = false; // anyHit == isShadow unless the scene has cutout materials (then shadow rays search the closest candidate)
+  // Lane flags live in ONE vector register and are changed with and/or. As separate bools they sit in scalar
+  // lane masks, and every divergent region that ends merges each of them with three scalar instructions — the leaf
+  // step and the triangle loop were mostly such merges (as many scalar as vector instructions in the whole kernel).
+  enum : unsigned int
+  {
+    ST_HAS_RAY    = 1u,  // the lane carries an unfinished ray
+    ST_ANY_HIT    = 2u,  // first accepted hit ends the ray (shadow rays, unless the scene has cutout materials)
+    ST_DONE       = 4u,  // the ray completed in this round and its result is not yet written
+    ST_SHADOW     = 8u,  // slot belongs to the shadow queue
+    ST_RETRACE    = 16u, // LDS stack overflow: the ray is re-traced by traceOverflowKernel with the spilling traverse()
+    ST_OVERFLOWED = 32u  // set while the overflowed ray is handed over (nothing is written for it here)
+  };
+  unsigned int state = 0u;
   unsigned int slot = 0;
   V3 org = v3(0.0f), dir = v3(0.0f);
   float tmin = 0.0f;
   TraceResult res; res.t = 0.0f; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
   TraceRay ray; ray.o = v3(0.0f); ray.d = v3(0.0f); ray.id = v3(0.0f);
-  WoopConstants woop; woop.zIsX = false; woop.zIsY = false; woop.flip = false; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
+  WoopConstants woop; woop.perm = 0u; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
   unsigned int guard = 0;
-  bool retrace = false; // LDS stack overflow: the ray is re-traced by traceOverflowKernel with the spilling traverse()
-  bool continue_after_overflow = false;
 
   for (;;)
   {
     // ---- refill idle lanes from the wave's pool ------------------------------------------------------
     {
-      const unsigned long long idle = __ballot(!hasRay);
+      const unsigned long long idle = __ballot(!(state & ST_HAS_RAY));
       if (idle != 0ull && !exhausted)
       {
         if (poolCount == 0u)
@@ -154,23 +163,21 @@ traceKernel(LaunchParams p, int depth)
         {
           const unsigned int rank = (unsigned int) __popcll(idle & laneBelow);
           const unsigned int take = min(poolCount, (unsigned int) __popcll(idle));
-          if (!hasRay && rank < take)
+          if (!(state & ST_HAS_RAY) && rank < take)
           {
             slot = poolBase + rank;
             float4 o, d;
-            if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; isShadow = false; }
-            else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; isShadow = true; }
-            anyHit = isShadow && !CUTOUT;
+            if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; state = ST_HAS_RAY; }
+            else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT); }
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
             setupRay(ray, org, dir);
             currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
-            hasRay = true;
           }
           poolBase += take; poolCount -= take;
         }
       }
-      if (__ballot(hasRay) == 0ull)
+      if (__ballot((state & ST_HAS_RAY) != 0u) == 0ull)
       {
         if (exhausted) break;
         continue; // pool was empty and the new ticket arrives next round
@@ -180,12 +187,12 @@ traceKernel(LaunchParams p, int depth)
     // ---- traverse until enough lanes have finished to be worth a refill ------------------------------
     for (;;)
     {
-      const int roundActive = __popcll(__ballot(hasRay));
+      const int roundActive = __popcll(__ballot((state & ST_HAS_RAY) != 0u));
       // All lanes descend inner nodes. Kept flat on purpose: the stack lives in LDS only here, push and pop are
       // straight-line predicated code (nested LDS/HBM stack selects compiled to ~70 scalar branch instructions
       // per node). A lane whose stack would overflow abandons this traversal and re-traces its ray with the
       // spilling traverse() (cold path, not taken on the LBVHs of the shipped scenes).
-      while (hasRay && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
+      while ((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
         // one WIDE node = the four grandchildren of binary node `node`: two levels per round of loads
         const float4* w = reinterpret_cast<const float4*>(p.wideNodes + 2 * (size_t) node);
@@ -210,14 +217,15 @@ traceKernel(LaunchParams p, int depth)
 #undef TWK_CE
         const int hits = (int) h0 + (int) h1 + (int) h2 + (int) h3;
         bool stop = (guard > (1u << 22));
+        bool overflow = false;
         if (hits > 0)
         {
           // nearest child next, the others pushed far-to-near; row TWK_TRACE_STACK_LDS of the LDS stack is a dummy
           // that absorbs the unconditional stores once the stack is full
           node = r0;
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r3; retrace = retrace || (hits > 3 && sp >= TWK_TRACE_STACK_LDS); sp += (hits > 3);
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r2; retrace = retrace || (hits > 2 && sp >= TWK_TRACE_STACK_LDS); sp += (hits > 2);
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r1; retrace = retrace || (hits > 1 && sp >= TWK_TRACE_STACK_LDS); sp += (hits > 1);
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r3; overflow |= (hits > 3) & (sp >= TWK_TRACE_STACK_LDS); sp += (hits > 3);
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r2; overflow |= (hits > 2) & (sp >= TWK_TRACE_STACK_LDS); sp += (hits > 2);
+          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r1; overflow |= (hits > 1) & (sp >= TWK_TRACE_STACK_LDS); sp += (hits > 1);
         }
         else
         {
@@ -225,17 +233,18 @@ traceKernel(LaunchParams p, int depth)
           sp = max(sp - 1, 0);
           node = ldsStack[sp * stride];
         }
-        if (stop || retrace) { hasRay = false; done = true; }
+        if (overflow) state |= ST_RETRACE;
+        if (stop | overflow) state = (state & ~ST_HAS_RAY) | ST_DONE;
         // Leave the node loop once most lanes are parked at a leaf: the stragglers resume in the next round
         // together with the lanes that come back from their leaf, instead of running at a few lanes per wave.
-        if (__popcll(__ballot(hasRay && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_FRACTION < roundActive) break;
+        if (__popcll(__ballot((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_FRACTION < roundActive) break;
       }
 
       // one leaf / instance-entry / instance-exit step per lane; lanes that left the node loop early are still
       // at an inner node and must NOT take this path (their `node` is not a leaf reference)
-      if (hasRay && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
+      if ((state & ST_HAS_RAY) && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
       {
-        bool pop = false;
+        unsigned int pop = 0u; // lane flag kept in a vector register, like `state`
         TWK_WAVE_STEP(leafWaveSteps)
         // Triangle range this lane tests in this round: the slots of a bottom-level leaf, or all triangles of a small
         // geometry tested right at its top-level leaf. ONE copy of the triangle loop serves both kinds of lanes.
@@ -245,7 +254,7 @@ traceKernel(LaunchParams p, int depth)
         {
           setupRay(ray, org, dir); // back to the world-space ray
           currentInstance = -1;
-          pop = true;
+          pop = 1u;
         }
         else
         {
@@ -268,24 +277,24 @@ traceKernel(LaunchParams p, int depth)
               // small geometry: its triangles are tested here, the lane stays in the top level (no descent, no sentinel)
               triFirst = __float_as_int(r3.y); triLast = triFirst + triCountInst - 1;
               triInstance = payload; triOrg = objOrg;
-              pop = true;
+              pop = 1u;
             }
             else
             {
               setupRay(ray, objOrg, objDir);
               currentInstance = payload;
-              retrace = retrace || (sp >= TWK_TRACE_STACK_LDS);
+              const bool full = (sp >= TWK_TRACE_STACK_LDS);
               ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = TWK_BVH_SENTINEL;
               ++sp;
               node = __float_as_int(r3.x);
-              if (retrace) { hasRay = false; done = true; }
+              if (full) state = (state & ~ST_HAS_RAY) | ST_DONE | ST_RETRACE;
             }
           }
           else
           {
             // a leaf of 1..8 consecutive triangle slots
             triFirst = payload & 0x0fffffff; triLast = triFirst + (payload >> 28);
-            pop = true;
+            pop = 1u;
           }
         }
 
@@ -296,42 +305,38 @@ traceKernel(LaunchParams p, int depth)
           if (COUNT) ++triCount;
           TWK_WAVE_STEP(triWaveSteps)
           float t, beta, gamma;
-          if (woopIntersect(woop, triOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
-          {
-            const int prim = __float_as_int(a.w);
-            const bool closer = (t < res.t) |
-                                ((t == res.t) & (res.instance >= 0) &
-                                 ((triInstance < res.instance) | ((triInstance == res.instance) & (prim < res.primitive))));
-            if (closer)
-            {
-              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = triInstance; res.primitive = prim; res.triangleSlot = ts;
-              if (anyHit) { pop = false; hasRay = false; done = true; break; }
-            }
-          }
+          const bool hit = woopIntersect(woop, triOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma);
+          const int prim = __float_as_int(a.w);
+          const bool closer = hit & ((t < res.t) |
+                                     ((t == res.t) & (res.instance >= 0) &
+                                      ((triInstance < res.instance) | ((triInstance == res.instance) & (prim < res.primitive)))));
+          res.t = closer ? t : res.t; res.beta = closer ? beta : res.beta; res.gamma = closer ? gamma : res.gamma;
+          res.instance = closer ? triInstance : res.instance; res.primitive = closer ? prim : res.primitive; res.triangleSlot = closer ? ts : res.triangleSlot;
+          if (closer & ((state & ST_ANY_HIT) != 0u)) { pop = 0u; state = (state & ~ST_HAS_RAY) | ST_DONE; break; }
         }
 
         if (pop)
         {
-          if (sp == 0) { hasRay = false; done = true; }
+          if (sp == 0) state = (state & ~ST_HAS_RAY) | ST_DONE;
           else { --sp; node = ldsStack[sp * stride]; }
         }
       }
 
       // write the result of rays that completed in this round
-      if (done)
+      if (state & ST_DONE)
       {
-        done = false;
-        if (retrace)
+        state &= ~ST_DONE;
+        const bool isShadow = (state & ST_SHADOW) != 0u;
+        if (state & ST_RETRACE)
         {
           // LDS stack overflow: hand the ray to traceOverflowKernel (spilling single-ray traversal), which runs
           // right behind this launch; nothing is written for it here.
-          retrace = false;
+          state = (state & ~ST_RETRACE) | ST_OVERFLOWED;
           const unsigned int k = atomicAdd(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3], 1u);
           p.overflowSlots[k] = slot;
-          continue_after_overflow = true;
         }
         if (COUNT) maxSteps = max(maxSteps, guard);
-        const bool ignoredCandidate = CUTOUT && !continue_after_overflow && res.instance >= 0 &&
+        const bool ignoredCandidate = CUTOUT && !(state & ST_OVERFLOWED) && res.instance >= 0 &&
                                       cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest);
         if (ignoredCandidate)
         {
@@ -341,9 +346,9 @@ traceKernel(LaunchParams p, int depth)
           res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
           setupRay(ray, org, dir);
           currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
-          hasRay = true;
+          state |= ST_HAS_RAY;
         }
-        else if (continue_after_overflow) { continue_after_overflow = false; }
+        else if (state & ST_OVERFLOWED) { state &= ~ST_OVERFLOWED; }
         else if (!isShadow)
         {
           p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
@@ -372,7 +377,7 @@ traceKernel(LaunchParams p, int depth)
         }
       }
 
-      const unsigned long long active = __ballot(hasRay);
+      const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
       if (active == 0ull) break;
       if (!exhausted && __popcll(active) < min(TWK_TRACE_REFILL, (int) ticketSize)) break;
     }
