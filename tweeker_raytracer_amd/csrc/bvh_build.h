@@ -12,7 +12,7 @@ public:
   // outWide receives, per inner node, the 128-byte wide node (two BvhNode halves) at outWide[2 * localIndex].
   // Bottom level over the triangles of one geometry. Writes max(1, numTriangles - 1) nodes at
   // outNodes[0..] whose inner references are nodeBase-relative absolutes and numTriangles triangle
-  // slots at outTriangles[3 * triangleBase ..] (+ the 144-byte shading records at outShadeTriangles[9 * triangleBase ..]). rootBounds receives the (padded) object-space box.
+  // slots at outTriangles[3 * triangleBase ..] (+ the 128-byte shading records at outShadeTriangles[TWK_SHADE_RECORD * triangleBase ..]). rootBounds receives the (padded) object-space box.
   hipError_t buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
                             BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6]);
 

@@ -287,9 +287,14 @@ __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4
   nodeLo[0] = lo; nodeHi[0] = hi;
 }
 
-// Triangle slots in leaf order: three float4 per slot, w of the first = primitive index. The same pass gathers the
-// shading attributes of the three vertices (36 floats = nine float4) next to each other per slot, so that shading
-// reads one contiguous 144-byte record instead of chasing indices → three 48-byte vertex records.
+// Triangle slots in leaf order: three float4 per slot, w of the first = primitive index. The same pass writes the
+// 128-byte shading record of the slot (one cache line, eight float4), ordered by who needs what, so that shading does
+// not chase indices → three 48-byte vertex records and fetches only the part its material uses — every fetch here is
+// one divergent lane address, and a CU takes one of those per clock (tools/gather_probe.hip):
+//   [0..2]  geometric normal cross(v1 - v0, v2 - v0) as closesthit.cu:150 computes it (same float operations, done
+//           once here), then the three vertex normals                                   — every hit
+//   [3..5.x] the three vertex tangents                                                  — GGX materials (TBN) only
+//   [5.y..7.y] the three vertex texture coordinates                                     — textured materials only
 __global__ void emitTrianglesKernel(const float* __restrict__ attributes, const unsigned int* __restrict__ indices,
                                     const unsigned long long* __restrict__ keys, int count, float4* __restrict__ triangles,
                                     float4* __restrict__ shadeTriangles)
@@ -304,16 +309,17 @@ __global__ void emitTrianglesKernel(const float* __restrict__ attributes, const 
   triangles[3 * (size_t) slot + 0] = make_float4(a[0], a[1], a[2], __uint_as_float(prim));
   triangles[3 * (size_t) slot + 1] = make_float4(b[0], b[1], b[2], 0.0f);
   triangles[3 * (size_t) slot + 2] = make_float4(c[0], c[1], c[2], 0.0f);
-  float4* out = shadeTriangles + 9 * (size_t) slot;
-  out[0] = make_float4(a[0], a[1], a[2],  a[3]);
-  out[1] = make_float4(a[4], a[5], a[6],  a[7]);
-  out[2] = make_float4(a[8], a[9], a[10], a[11]);
-  out[3] = make_float4(b[0], b[1], b[2],  b[3]);
-  out[4] = make_float4(b[4], b[5], b[6],  b[7]);
-  out[5] = make_float4(b[8], b[9], b[10], b[11]);
-  out[6] = make_float4(c[0], c[1], c[2],  c[3]);
-  out[7] = make_float4(c[4], c[5], c[6],  c[7]);
-  out[8] = make_float4(c[8], c[9], c[10], c[11]);
+  const V3 v0 = v3(a[0], a[1], a[2]), v1 = v3(b[0], b[1], b[2]), v2 = v3(c[0], c[1], c[2]);
+  const V3 ng = cross(v1 - v0, v2 - v0);
+  float4* out = shadeTriangles + TWK_SHADE_RECORD * (size_t) slot;
+  out[0] = make_float4(ng.x, ng.y, ng.z, a[6]);
+  out[1] = make_float4(a[7], a[8], b[6], b[7]);
+  out[2] = make_float4(b[8], c[6], c[7], c[8]);
+  out[3] = make_float4(a[3], a[4], a[5], b[3]);
+  out[4] = make_float4(b[4], b[5], c[3], c[4]);
+  out[5] = make_float4(c[5], a[9], a[10], a[11]);
+  out[6] = make_float4(b[9], b[10], b[11], c[9]);
+  out[7] = make_float4(c[10], c[11], 0.0f, 0.0f);
 }
 
 #define BVH_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
@@ -383,7 +389,7 @@ hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attribute
   hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
   hipLaunchKernelGGL(triangleBoxesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, numTriangles, m_primLo, m_primHi, m_bounds);
   BVH_CHECK(buildFromBoxes(stream, numTriangles, outNodes, outWide, nodeBase, 0, triangleBase));
-  hipLaunchKernelGGL(emitTrianglesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, m_keysOut, numTriangles, outTriangles + 3 * (size_t) triangleBase, outShadeTriangles + 9 * (size_t) triangleBase);
+  hipLaunchKernelGGL(emitTrianglesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, m_keysOut, numTriangles, outTriangles + 3 * (size_t) triangleBase, outShadeTriangles + TWK_SHADE_RECORD * (size_t) triangleBase);
   BVH_CHECK(hipGetLastError());
   float4 lo, hi;
   BVH_CHECK(hipMemcpyAsync(&lo, m_nodeLo, sizeof(float4), hipMemcpyDeviceToHost, stream));

@@ -703,7 +703,7 @@ int twk_build(TwkDevice dev)
   HIP_TRY(hipMalloc(&dev->d_nodes, sizeof(BvhNode) * numNodes));
   HIP_TRY(hipMalloc(&dev->d_wideNodes, sizeof(BvhNode) * 2 * numNodes));
   HIP_TRY(hipMalloc(&dev->d_triangles, sizeof(float4) * 3 * numTris));
-  HIP_TRY(hipMalloc(&dev->d_shadeTriangles, sizeof(float4) * 9 * numTris));
+  HIP_TRY(hipMalloc(&dev->d_shadeTriangles, sizeof(float4) * TWK_SHADE_RECORD * numTris));
   HIP_TRY(hipMalloc(&dev->d_instances, sizeof(DevInstance) * numInstances));
   for (const GeometryHost& g : dev->geometries)
   {

@@ -80,6 +80,7 @@ struct DevInstance
 // Geometries with at most this many triangles (planes, the light quad, boxes' faces ...) have no bottom-level
 // descent: entering, one node, two leaves and leaving collapse into one step at the top-level leaf.
 #define TWK_INLINE_TRIANGLES 4
+#define TWK_SHADE_RECORD 8 // float4 per shading record
 
 struct DevTexture
 {
@@ -109,7 +110,7 @@ struct LaunchParams
   const BvhNode*     nodes;          // binary nodes (single-ray traversal: query kernel, overflow fallback, tail kernel)
   const BvhNode*     wideNodes;      // 4-ary nodes, 128 bytes = 2 BvhNode slots per inner node index (persistent trace kernel; layout: bvh_build.hip writeWideNode)
   const float4*      triangles;      // 3 per triangle slot
-  const float4*      shadeTriangles; // 9 per triangle slot: the three vertices' vertex, tangent, normal, texcoord
+  const float4*      shadeTriangles; // TWK_SHADE_RECORD (8) per triangle slot, 128 B: geometric normal + the three vertices' normals | tangents | texcoords (bvh_build.hip emitTrianglesKernel)
   const DevInstance* instances;
   const float*       attributes;     // 12 floats per vertex
   const unsigned int* indices;

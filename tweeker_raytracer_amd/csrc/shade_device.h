@@ -521,23 +521,37 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   {
     // ---- __closesthit__radiance, closesthit.cu:126-305
     const DevInstance& inst = p.instances[instanceIndex];
-    // the three vertices' attributes, gathered per triangle slot at build time (bvh_build.hip emitTrianglesKernel)
-    const float4* sv = p.shadeTriangles + 9 * (size_t) __float_as_int(hit.w);
-    const float4 s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3], s4 = sv[4], s5 = sv[5], s6 = sv[6], s7 = sv[7], s8 = sv[8];
+    // The slot's shading record (bvh_build.hip emitTrianglesKernel): geometric normal and vertex normals for every
+    // hit; tangents and texture coordinates are fetched only by the materials that read them (the tangent feeds the
+    // GGX tangent space only, closesthit.cu:161 computes it for all) — each fetch is one divergent lane address.
+    const float4* sv = p.shadeTriangles + TWK_SHADE_RECORD * (size_t) __float_as_int(hit.w);
+    const float4 s0 = sv[0], s1 = sv[1], s2 = sv[2];
+    const DevMaterial& material = p.materials[inst.material];
+    const bool needTangent  = material.indexBSDF >= 3;
+    const bool needTexcoord = material.textureAlbedo != 0;
 
     const float beta = hit.y, gamma = hit.z;
     const float alpha = 1.0f - beta - gamma;
 
-    const V3 v0 = v3(s0.x, s0.y, s0.z), v1 = v3(s3.x, s3.y, s3.z), v2 = v3(s6.x, s6.y, s6.z);
-    const V3 ng = cross(v1 - v0, v2 - v0);
-    const V3 tg = v3(s0.w, s1.x, s1.y) * alpha + v3(s3.w, s4.x, s4.y) * beta + v3(s6.w, s7.x, s7.y) * gamma;
-    const V3 ns = v3(s1.z, s1.w, s2.x) * alpha + v3(s4.z, s4.w, s5.x) * beta + v3(s7.z, s7.w, s8.x) * gamma;
+    const V3 ng = v3(s0.x, s0.y, s0.z);                                               // closesthit.cu:150
+    const V3 ns = v3(s0.w, s1.x, s1.y) * alpha + v3(s1.z, s1.w, s2.x) * beta + v3(s2.y, s2.z, s2.w) * gamma;
 
     SurfaceState state;
-    state.texcoord = v3(s2.y, s2.z, s2.w) * alpha + v3(s5.y, s5.z, s5.w) * beta + v3(s8.y, s8.z, s8.w) * gamma;
+    state.texcoord = v3(0.0f);
+    state.tangent  = v3(0.0f);
+    if (needTangent)
+    {
+      const float4 s3 = sv[3], s4 = sv[4], s5 = sv[5];
+      const V3 tg = v3(s3.x, s3.y, s3.z) * alpha + v3(s3.w, s4.x, s4.y) * beta + v3(s4.z, s4.w, s5.x) * gamma;
+      state.tangent = normalize(transformVector(inst.objectToWorld, tg));
+    }
+    if (needTexcoord)
+    {
+      const float4 s5 = sv[5], s6 = sv[6], s7 = sv[7];
+      state.texcoord = v3(s5.y, s5.z, s5.w) * alpha + v3(s6.x, s6.y, s6.z) * beta + v3(s6.w, s7.x, s7.y) * gamma;
+    }
 
     state.normalGeo = normalize(transformNormal(inst.worldToObject, ng));
-    state.tangent   = normalize(transformVector(inst.objectToWorld, tg));
     state.normal    = normalize(transformNormal(inst.worldToObject, ns));
 
     prd.distance = hit.x;
@@ -575,7 +589,6 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
       prd.f_over_pdf = v3(0.0f);
       prd.pdf        = 0.0f;
 
-      const DevMaterial& material = p.materials[inst.material];
       state.albedo = v3(material.albedo[0], material.albedo[1], material.albedo[2]);
       if (material.textureAlbedo != 0)
       {

@@ -27,10 +27,10 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
   const DevInstance& inst = p.instances[res.instance];
   const DevMaterial& material = p.materials[inst.material];
   if (material.textureCutout == 0) return false;
-  const float4* sv = p.shadeTriangles + 9 * (size_t) res.triangleSlot;
-  const float4 s2 = sv[2], s5 = sv[5], s8 = sv[8];
+  const float4* sv = p.shadeTriangles + TWK_SHADE_RECORD * (size_t) res.triangleSlot;
+  const float4 s5 = sv[5], s6 = sv[6], s7 = sv[7];
   const float alpha = 1.0f - res.beta - res.gamma;
-  const V3 texcoord = v3(s2.y, s2.z, s2.w) * alpha + v3(s5.y, s5.z, s5.w) * res.beta + v3(s8.y, s8.z, s8.w) * res.gamma;
+  const V3 texcoord = v3(s5.y, s5.z, s5.w) * alpha + v3(s6.x, s6.y, s6.z) * res.beta + v3(s6.w, s7.x, s7.y) * res.gamma;
   const float opacity = intensity(v3(tex2D(p.textures[1], texcoord.x, texcoord.y)));
   if (!(opacity < 1.0f)) return false;
   float draw;
