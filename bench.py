@@ -89,6 +89,9 @@ def main():
     info = app.info
     dev = twk.Device(ordinal=local_rank, index=rank, count=n_gpus, miss=info.miss)
     app.initDevice(dev, distribution=1 if n_gpus > 1 else 0)
+    # path streams for the largest pass the timed loop will issue (twk_launch batches up to 64 iterations per pass):
+    # allocated here, not inside the timed region
+    dev.reserveLaunchBatch(min(64, max(1, args.steps)))
     lw = dev.launchWidth
 
     # The accumulation buffer is a torch tensor so RCCL can send it without a copy.
@@ -109,6 +112,7 @@ def main():
         """N > 1 only, after the timed region: the composed image must equal a single-device render of the frame."""
         single = twk.Device(ordinal=local_rank, miss=info.miss)
         app.initDevice(single)
+        single.setLaunchBatch(max(1, 64 // n_gpus))  # the frame is n_gpus times a rank's share: same stream memory as a rank
         for it in range(0, args.warmup + args.steps):  # the accumulator keeps the warm-up iterations, like the ranks' buffers
             single.render(it)
         ref_img = single.getOutputBufferHost()

@@ -199,9 +199,12 @@ int twk_clear_scene(TwkDevice dev);
 int twk_launch(TwkDevice dev, unsigned int iterationIndex);
 int twk_sync(TwkDevice dev);                                  /* ≙ Device::synchronizeStream */
 /* twk_launch is asynchronous and deferred: consecutive iteration indices are rendered together, up to `iterations`
- * samples per pixel per wavefront pass (default 16), as soon as the batch is full or any other call observes the
- * device. The image is bit-identical to one pass per iteration; 1 restores strict one-launch-per-call behaviour. */
+ * samples per pixel per wavefront pass (1..64, default 64; 344 bytes of path streams per sample and pixel), as soon
+ * as the batch is full or any other call observes the device. The image is bit-identical to one pass per iteration; 1 restores strict one-launch-per-call behaviour. */
 int twk_set_launch_batch(TwkDevice dev, int iterations);
+/* The path streams of a pass are allocated on demand and grow with the largest pass seen; this allocates them up
+ * front for passes of `iterations` samples per pixel, so that no allocation falls into a timed or interactive loop. */
+int twk_reserve_launch_batch(TwkDevice dev, int iterations);
 
 /* Output. With distribution 0 the buffer is W×H (≙ outputBuffer); with distribution 1 it is the
  * packed launchWidth×H local tile buffer (≙ texelBuffer, DeviceMultiGPULocalCopy.cpp:109-172). */

@@ -7,7 +7,7 @@ TAG=${1:-pmc}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-ARGS="--steps 32 --warmup 16 --no-cpu-baseline --no-roofline $*"
+ARGS="--steps 64 --warmup 64 --no-cpu-baseline --no-roofline $*"
 run() { # name counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"

@@ -24,7 +24,7 @@ res = {
     "fetch_correction": 2.0,
     "hbm_bytes_per_launch": (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0,
     "l2_hit_rate": per.get("TCC_HIT_sum", 0) / max(1.0, per.get("TCC_HIT_sum", 0) + per.get("TCC_MISS_sum", 0)),
-    "note": "launches of 16 iterations (default batch); separate --pmc passes for FETCH_SIZE and WRITE_SIZE; counters include Infinity-Cache hits (memory-side of L2)",
+    "note": "launches of 64 iterations (default batch); separate --pmc passes for FETCH_SIZE and WRITE_SIZE; counters include Infinity-Cache hits (memory-side of L2)",
 }
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))

@@ -117,7 +117,7 @@ struct TwkDevice_t
   int   tailDepth = 0; // > 0: bounces >= tailDepth run in the tail kernel (TWK_TAIL_DEPTH); measured no faster than the wavefront at 1920x1080, kept off
   // Deferred launches: twk_launch only records the iteration; consecutive iterations are rendered together as one
   // wavefront pass of up to batchMax samples per pixel when the batch is full or anything observes the device.
-  int   batchMax = 16;
+  int   batchMax = 64;
   unsigned int pendingFirst = 0;
   int   pendingCount = 0;
   int   allocatedPaths = 0;
@@ -234,10 +234,12 @@ static void refreshParams(TwkDevice dev)
 
 static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * 6; } // 24 KiB LDS stack per block → 6 blocks per CU
 
-static int ensureStreams(TwkDevice dev)
+// `samples`: samples per pixel the next wavefront pass carries; the path streams grow to what passes actually need
+// (a 64-sample pass of a 1920x1080 frame takes 46 GB, a handle that renders two iterations takes 1.4 GB).
+static int ensureStreams(TwkDevice dev, int samples = 1)
 {
   const int numPixels = dev->launchWidth * dev->state.resolution[1];
-  const int numPaths  = numPixels * (dev->batchMax > 1 ? dev->batchMax : 1);
+  const int numPaths  = numPixels * (samples > 1 ? samples : 1);
   if (numPixels > dev->allocatedPixels || dev->d_outputInternal == nullptr)
   {
     freeDevice(dev->d_outputInternal);
@@ -387,7 +389,7 @@ static void calculateSphericalCDF(const float* rgba, unsigned int width, unsigne
 static int flushPending(TwkDevice dev)
 {
   int rc;
-  if ((rc = ensureStreams(dev))) return rc;
+  if ((rc = ensureStreams(dev, dev->pendingCount))) return rc;
   refreshParams(dev);
   LaunchParams& p = dev->params;
   p.iterationIndex = dev->pendingFirst;
@@ -477,7 +479,7 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
   }
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
-  if (const char* e = getenv("TWK_BATCH")) { const int b = atoi(e); dev->batchMax = (b < 1) ? 1 : ((b > 16) ? 16 : b); }
+  if (const char* e = getenv("TWK_BATCH")) { const int b = atoi(e); dev->batchMax = (b < 1) ? 1 : ((b > 64) ? 64 : b); }
   *out = dev;
   return TWK_SUCCESS;
 }
@@ -791,10 +793,18 @@ int twk_launch(TwkDevice dev, unsigned int iterationIndex)
 int twk_set_launch_batch(TwkDevice dev, int iterations)
 {
   int rc = activate(dev, "twk_set_launch_batch"); if (rc) return rc;
-  if (iterations < 1 || iterations > 16) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_launch_batch: 1..16 iterations per pass");
+  if (iterations < 1 || iterations > 64) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_launch_batch: 1..64 iterations per pass");
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->batchMax = iterations;
   return TWK_SUCCESS;
+}
+
+int twk_reserve_launch_batch(TwkDevice dev, int iterations)
+{
+  int rc = activate(dev, "twk_reserve_launch_batch"); if (rc) return rc;
+  if (iterations < 1 || iterations > 64) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_reserve_launch_batch: 1..64 iterations per pass");
+  if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_reserve_launch_batch: twk_set_state first");
+  return ensureStreams(dev, iterations);
 }
 
 int twk_sync(TwkDevice dev)

@@ -114,8 +114,12 @@ class Device:
         L.check(L.lib.twk_launch(self._h, C.c_uint(int(iterationIndex))))
 
     def setLaunchBatch(self, iterations):
-        """Iterations rendered together per wavefront pass (1..16); results do not depend on it."""
+        """Iterations rendered together per wavefront pass (1..64); results do not depend on it."""
         L.check(L.lib.twk_set_launch_batch(self._h, int(iterations)))
+
+    def reserveLaunchBatch(self, iterations):
+        """Allocate the path streams for passes of `iterations` samples per pixel now instead of on demand."""
+        L.check(L.lib.twk_reserve_launch_batch(self._h, int(iterations)))
 
     def synchronizeStream(self):
         L.check(L.lib.twk_sync(self._h))
