@@ -142,3 +142,67 @@ def test_coincident_geometry_ties_and_lds_stack_overflow(twk, orc):
     assert st["overflowRays"] > 0, "the scene is built to overflow the LDS stack"
     assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(ref.getOutputBufferHost()))
     dev.close()
+
+
+def _random_rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize("seed,offset", [(1, (0.0, 0.0, 0.0)), (2, (0.0, 0.0, 0.0)), (3, (900.0, -350.0, 1700.0)), (4, (-64.0, 8192.0, 33.0))])
+def test_random_scenes_far_from_the_origin(twk, orc, seed, offset):
+    """Randomised scenes through the PERSISTENT wide-node kernel (twk_launch; twk_trace_rays walks the binary tree):
+    triangle soups with triangle sizes over three decades, instances with random rotation / non-uniform scale / shear,
+    the whole scene optionally translated far from the origin, where box culling has the least slack relative to
+    the rounding of o/d. Images must equal the oracle's brute-force traversal bit for bit: a culled hit shows up as a
+    differing pixel."""
+    rng = np.random.default_rng(seed)
+    geos = []
+    for ntri in (7, 60, 300, 1500):
+        centre = rng.uniform(-1, 1, (ntri, 1, 3))
+        size = 10.0 ** rng.uniform(-2.5, -0.2, (ntri, 1, 1))
+        v = (centre + size * rng.normal(size=(ntri, 3, 3))).astype(np.float32).reshape(-1, 3)
+        geos.append((_attrs(v), np.arange(ntri * 3, dtype=np.uint32)))
+    # a floor under everything so that most paths bounce
+    floor = np.array([[-6, -1.3, -6], [6, -1.3, -6], [6, -1.3, 6], [-6, -1.3, -6], [6, -1.3, 6], [-6, -1.3, 6]], np.float32)
+    geos.append((_attrs(floor), np.arange(6, dtype=np.uint32)))
+    off = np.array(offset)
+    inst = []
+    for k in range(14):
+        m = _random_rotation(rng) @ np.diag(rng.uniform(0.3, 1.4, 3)) @ (np.eye(3) + np.triu(rng.uniform(-0.3, 0.3, (3, 3)), 1))
+        t = np.concatenate([m, (rng.uniform(-2.2, 2.2, 3) + off)[:, None]], 1).astype(np.float32)
+        inst.append((k % 4, t.reshape(-1), k % 3))
+    t = np.concatenate([np.eye(3), off[:, None]], 1).astype(np.float32)
+    inst.append((4, t.reshape(-1), 0))
+
+    w, h = 40, 30
+    cam = twk.camera_frustum(tuple(float(c) for c in off), 0.75, 0.55, 55.0, 7.0, w / h)
+    light = twk.LightDefinition()
+    light.type = 0
+    light.area = 12.566371
+    light.emission[0] = light.emission[1] = light.emission[2] = 1.0
+    mats = [_material(twk), _material(twk, 1, (0.9, 0.9, 0.9)), _material(twk, 3, (0.8, 0.7, 0.3))]
+    imgs = []
+    for r in (twk.Device(ordinal=0, miss=1), orc.Oracle(miss=1)):
+        r.setState(_state(twk, w, h, depth=4))
+        r.initCameras([cam])
+        r.initLights([light])
+        r.initMaterials(mats)
+        for a, i in geos:
+            r.addGeometry(a, i)
+        for g, tr, m in inst:
+            r.addInstance(g, tr, m)
+        r.build()
+        if hasattr(r, "setTraceMode"):
+            r.setTraceMode(False)  # brute force over all triangles of all instances
+        for it in range(3):
+            r.render(it)
+        imgs.append(r.getOutputBufferHost())
+    gpu, cpu = imgs
+    assert np.isfinite(cpu).all() and (cpu[..., :3] > 0).mean() > 0.5
+    mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+    assert mism == 0, f"{mism} of {w * h} pixels differ"
