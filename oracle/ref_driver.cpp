@@ -17,6 +17,11 @@
 #include "shaders/shader_common.h"
 #include "shaders/random_number_generators.h"
 #include "shaders/vertex_attributes.h"
+#include "shaders/camera_definition.h"
+#include "shaders/light_definition.h"
+#include "shaders/function_indices.h"
+#include "inc/TonemapperGUI.h"
+#include <cstddef>
 #include "inc/SceneGraph.h"
 #include "inc/Camera.h"
 #include "inc/Parser.h"
@@ -177,6 +182,52 @@ int ref_transform_stack(const float* ops, int numOps, float trafo[12])
   };
   memcpy(trafo, t, sizeof(t));
   return 0;
+}
+
+
+// Layout of the reference's plain structs that cross the replaced boundary, as its own headers define them:
+// out[] = size, then the offset of every member in declaration order. which: 0 CameraDefinition
+// (shaders/camera_definition.h), 1 LightDefinition (shaders/light_definition.h), 2 TriangleAttributes
+// (shaders/vertex_attributes.h), 3 TonemapperGUI (inc/TonemapperGUI.h). Returns the number of values written.
+int ref_struct_layout(int which, int* out, int capacity)
+{
+  int n = 0;
+#define PUT(v) do { if (n < capacity) out[n] = (int) (v); ++n; } while (0)
+  switch (which)
+  {
+    case 0:
+      PUT(sizeof(CameraDefinition));
+      PUT(offsetof(CameraDefinition, P)); PUT(offsetof(CameraDefinition, U)); PUT(offsetof(CameraDefinition, V)); PUT(offsetof(CameraDefinition, W));
+      break;
+    case 1:
+      PUT(sizeof(LightDefinition));
+      PUT(offsetof(LightDefinition, type)); PUT(offsetof(LightDefinition, position)); PUT(offsetof(LightDefinition, vecU));
+      PUT(offsetof(LightDefinition, vecV)); PUT(offsetof(LightDefinition, normal)); PUT(offsetof(LightDefinition, area));
+      PUT(offsetof(LightDefinition, emission)); PUT(offsetof(LightDefinition, unused0)); PUT(offsetof(LightDefinition, unused1)); PUT(offsetof(LightDefinition, unused2));
+      break;
+    case 2:
+      PUT(sizeof(TriangleAttributes));
+      PUT(offsetof(TriangleAttributes, vertex)); PUT(offsetof(TriangleAttributes, tangent)); PUT(offsetof(TriangleAttributes, normal)); PUT(offsetof(TriangleAttributes, texcoord));
+      break;
+    case 3:
+      PUT(sizeof(TonemapperGUI));
+      PUT(offsetof(TonemapperGUI, gamma)); PUT(offsetof(TonemapperGUI, whitePoint)); PUT(offsetof(TonemapperGUI, colorBalance));
+      PUT(offsetof(TonemapperGUI, burnHighlights)); PUT(offsetof(TonemapperGUI, crushBlacks)); PUT(offsetof(TonemapperGUI, saturation)); PUT(offsetof(TonemapperGUI, brightness));
+      break;
+    default: return -1;
+  }
+#undef PUT
+  return n;
+}
+
+// FunctionIndex / LightType values the C ABI mirrors as plain ints (shaders/function_indices.h, light_definition.h).
+int ref_enum_values(int* out, int capacity)
+{
+  const int v[] = {INDEX_BRDF_DIFFUSE, INDEX_BRDF_SPECULAR, INDEX_BSDF_SPECULAR, INDEX_BRDF_GGX_SMITH, INDEX_BSDF_GGX_SMITH,
+                   LIGHT_ENVIRONMENT, LIGHT_PARALLELOGRAM};
+  const int n = (int) (sizeof(v) / sizeof(v[0]));
+  for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];
+  return n;
 }
 
 } // extern "C"
