@@ -305,8 +305,8 @@ int twk_app_screenshot_path(TwkApp app, int tonemap, char* out, size_t capacity)
  * 8-bit RGB PNG (stored deflate blocks) and Radiance RGBE .hdr (flat scanlines). `bottomUp` != 0: row 0 of the
  * buffer is the BOTTOM row of the picture (the renderer's convention, IL_ORIGIN_LOWER_LEFT). */
 /* ≙ Picture::load + the format expansion of Texture::create* (Picture.cpp:231-560, Texture.cpp:933-1042): decode an
- * image file to RGBA32F, row 0 = bottom row, ready for twk_init_texture. PNG, Radiance .hdr, PFM (DevIL is not
- * available; JPEG is not decoded). Two-call protocol: with rgba == NULL only width/height are returned; otherwise
+ * image file to RGBA32F, row 0 = bottom row, ready for twk_init_texture. PNG, baseline JPEG (libjpeg's default
+ * decode path, byte-exact), Radiance .hdr, PFM — DevIL is not available. Two-call protocol: with rgba == NULL only width/height are returned; otherwise
  * capacityFloats must be >= width*height*4. */
 int twk_load_image(const char* path, int* width, int* height, float* rgba, size_t capacityFloats);
 /* File name given with "envMap" in the system description (Application.cpp:1151-1156), "" if none. */

@@ -98,9 +98,9 @@ def test_png_palette_and_errors(twk, tmp_path):
     bad = bytearray(good)
     bad[40] ^= 0xff  # flips a byte inside a chunk: the checksum no longer matches
     (tmp_path / "bad.png").write_bytes(bytes(bad))
-    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(64))
+    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0\x00\x10" + bytes(14) + b"\xff\xd9")
     (tmp_path / "junk.bin").write_bytes(b"hello world, not a picture")
-    for name, text in (("bad.png", "checksum"), ("photo.jpg", "JPEG"), ("junk.bin", "unknown image format"), ("missing.png", "cannot read")):
+    for name, text in (("bad.png", "checksum"), ("photo.jpg", "JPEG: no scan"), ("junk.bin", "unknown image format"), ("missing.png", "cannot read")):
         with pytest.raises(twk.TwkError, match=text):
             twk.load_image(str(tmp_path / name))
 
@@ -176,3 +176,38 @@ def test_env_map_name_of_the_system_description(twk):
     scene = open(scene_path("scene_rtigo3_cornell_box_c1.txt")).read()
     assert twk.Application(system_text="miss 2\nenvMap /data/sky_latlong.hdr\n", scene_text=scene).environment == "/data/sky_latlong.hdr"
     assert twk.Application(system_text="miss 1\n", scene_text=scene).environment == ""
+
+
+def test_jpeg_reader_matches_libjpeg(twk, tmp_path):
+    """Baseline JPEG through twk_load_image == Pillow's libjpeg decode, byte for byte: greyscale, 4:4:4, 4:2:2, 4:2:0,
+    sizes that are not multiples of the MCU, optimised Huffman tables, restart intervals, several qualities.
+    Progressive files are refused."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(12)
+
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 5.0), 128 + 90 * np.cos((x + y) / 9.0), (x * 255 / max(1, w - 1))], -1)
+        return np.clip(base + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+
+    cases = [((16, 16), dict(quality=90, subsampling=0)), ((37, 29), dict(quality=75, subsampling=0)),
+             ((33, 50), dict(quality=85, subsampling=1)), ((64, 48), dict(quality=60, subsampling=2)),
+             ((45, 71), dict(quality=92, subsampling=2, optimize=True)), ((9, 5), dict(quality=80, subsampling=2)),
+             ((1, 1), dict(quality=80, subsampling=2)), ((120, 200), dict(quality=70, subsampling=1, restart_marker_blocks=3)),
+             ((88, 64), dict(quality=50, subsampling=2, restart_marker_rows=1))]
+    for k, ((h, w), opts) in enumerate(cases):
+        p = str(tmp_path / f"c{k}.jpg")
+        Image.fromarray(picture(h, w)).save(p, **opts)
+        expect = np.asarray(Image.open(p).convert("RGB"))
+        got = twk.load_image(p)
+        assert got.shape == (h, w, 4) and (got[..., 3] == 1).all()
+        assert np.array_equal(got[::-1, :, :3], expect.astype(np.float32) / np.float32(255)), (k, opts)
+    p = str(tmp_path / "grey.jpg")
+    Image.fromarray(picture(40, 31)[..., 0]).save(p, quality=88)
+    expect = np.asarray(Image.open(p))
+    got = twk.load_image(p)
+    assert np.array_equal(got[::-1, :, 0], expect.astype(np.float32) / np.float32(255)) and np.array_equal(got[..., 0], got[..., 2])
+    p = str(tmp_path / "prog.jpg")
+    Image.fromarray(picture(32, 32)).save(p, progressive=True)
+    with pytest.raises(twk.TwkError, match="progressive"):
+        twk.load_image(p)

@@ -65,8 +65,8 @@ bool parseCommandLine(int argc, char* argv[], Options& o)
 
 // ≙ Application::createPictures (Application.cpp:679-699) + Raytracer::initTextures: the two hard-coded material
 // pictures and, for miss 2, the environment map named by "envMap". A picture that cannot be read is reported and
-// skipped (materials that ask for it then render untextured); JPEG is not decodable here, so the albedo picture is
-// also looked up as ./NVIDIA_Logo.png.
+// skipped (materials that ask for it then render untextured); a progressive JPEG is not decodable here, so the
+// albedo picture is also looked up as ./NVIDIA_Logo.png.
 struct PictureFile { int slot; std::vector<std::string> candidates; };
 
 bool loadPicture(const PictureFile& picture, int& width, int& height, std::vector<float>& rgba)
