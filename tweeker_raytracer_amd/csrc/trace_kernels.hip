@@ -2,12 +2,12 @@
 // closesthit.cu:281-286 shadow rays; the traversal itself lives in closed libnvoptix.so.1).
 //
 // One persistent launch per bounce serves BOTH ray kinds: the closest-hit rays of bounce k+1 and the
-// any-hit shadow rays emitted by the shading of bounce k. Waves pull 64 consecutive queue slots with
-// one atomic ticket per wave, so ray and hit records are read and written as full 1-KiB coalesced
-// wave accesses (two 16-byte loads per lane). Each lane walks the two-level BVH2 with its own stack:
-// the first TWK_TRACE_STACK_LDS entries in LDS laid out [entry][lane] (bank = lane, conflict free),
-// overflow in a per-lane HBM segment. Instances are entered by transforming the ray into object
-// space (t is preserved), exactly what an OptiX IAS→GAS descent does.
+// any-hit shadow rays emitted by the shading of bounce k. A wave owns contiguous ranges of queue slots (mostly
+// dealt statically, the rest in tickets of 64 from one atomic counter) and hands them to its lanes as they fall
+// idle. Each lane walks the two-level BVH with its own stack — 4-ary wide nodes, TWK_TRACE_STACK_LDS entries in
+// LDS laid out [entry][lane] (bank = lane, conflict free); a ray whose stack would overflow is handed to
+// traceOverflowKernel, whose single-ray traverse() over the binary nodes continues the stack in HBM. Instances are
+// entered by transforming the ray into object space (t is preserved), exactly what an OptiX IAS→GAS descent does.
 //
 // Triangle test: watertight algorithm of Woop, Benthin, Wald (JCGT 2013), single precision with the
 // double fallback on zero edge functions, no fused multiply-add. Ties in t go to the smaller
@@ -58,7 +58,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // (depth & 1), slots [numClosest, numClosest + numShadow) the shadow rays emitted by shade(depth - 1).
 //
 // Structure (persistent threads with per-lane refill, after Aila & Laine 2009, re-tiled for 64-wide waves):
-//   * a wave owns a small pool of consecutive queue slots, refilled 64 at a time with ONE atomic ticket;
+//   * a wave owns a pool of consecutive queue slots: a static share first, then tickets of 64 from ONE atomic counter;
 //   * every lane carries one ray; when fewer than TWK_TRACE_REFILL lanes still hold a ray the wave leaves the
 //     traversal loop and hands fresh slots from its pool to the idle lanes (ballot + prefix popcount, no atomics) —
 //     ray lengths on this workload range from 3 to 100+ node visits, and without refill the wave idles on its
@@ -292,7 +292,7 @@ traceKernel(LaunchParams p, int depth)
           }
           else
           {
-            // a leaf of 1..8 consecutive triangle slots
+            // a leaf of 1..8 consecutive triangle slots (bvh_build.hip: at most TWK_MAX_LEAF, default 2)
             triFirst = payload & 0x0fffffff; triLast = triFirst + (payload >> 28);
             pop = 1u;
           }
