@@ -226,3 +226,22 @@ def test_error_paths(twk):
     with pytest.raises(twk.TwkError):
         twk.Device(ordinal=99)
     dev.close()
+
+
+def test_tail_kernel_option_does_not_change_the_image(twk, monkeypatch):
+    """TWK_TAIL_DEPTH=n (off by default): bounces >= n of every surviving path run in one persistent kernel
+    instead of per-depth launches. Same device functions, same bits."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (160, 90))
+    imgs = []
+    for tail in (None, "2", "5"):
+        if tail is None:
+            monkeypatch.delenv("TWK_TAIL_DEPTH", raising=False)
+        else:
+            monkeypatch.setenv("TWK_TAIL_DEPTH", tail)
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        app.initDevice(dev)
+        for it in range(3):
+            dev.render(it)
+        imgs.append(dev.getOutputBufferHost())
+        dev.close()
+    assert np.array_equal(_bits(imgs[0]), _bits(imgs[1])) and np.array_equal(_bits(imgs[0]), _bits(imgs[2]))
