@@ -212,6 +212,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "note": "achieved counts every node / triangle / instance fetch at full record size (SURVEY 8d: cache hits do not reduce them); the 19 MB scene is served from L2 / Infinity Cache, so frac can exceed 1 - the HBM-side bytes are `traffic` (PMC); what bounds the kernel: DESIGN.md 4.1",
             "algorithmic_bytes_per_launch": algo_bytes / max(1, trace_launches),
             "avg_launch_ms": trace_ms / max(1, trace_launches),
             "launches": trace_launches,
