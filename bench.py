@@ -52,7 +52,8 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene_rtigo3_cornell_box.txt"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the oracle sample")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a share of 16 cores)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 path on ONE GPU: all ranks share device 0, the gather goes over gloo through host memory")
     args = ap.parse_args()
@@ -228,34 +229,42 @@ def main():
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         }
 
-    # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same workload ----------
+    # ---- CPU baseline: the oracle on the host cores, a bounded sample of the same workload -------------
     if not args.no_cpu_baseline and rank == 0 and n_gpus == 1:
         from oracle import orc
         ref = orc.Oracle(miss=info.miss)
         ref.loadApplication(app)
-        # calibrate on 16 rows, then take as many full-width rows of iteration 0 as fit the time budget
+        try:
+            allowed = len(os.sched_getaffinity(0))
+        except AttributeError:
+            allowed = os.cpu_count() or 1
+        threads = max(1, min(args.cpu_threads, allowed))
+        # first call builds the oracle's BVH and calibrates: 16 rows of iteration 0
         y0 = height // 2 - 8
+        ref.render(0, rect=(0, y0, width, y0 + 16), threads=threads)
         tc = time.perf_counter()
-        ref.render(0, rect=(0, y0, width, y0 + 16))
+        ref.render(0, rect=(0, y0, width, y0 + 16), threads=threads)
         per_row = (time.perf_counter() - tc) / 16.0
-        rows = int(max(16, min(height, args.cpu_seconds / max(per_row, 1e-9))))
-        y0 = max(0, height // 2 - rows // 2)
+        # whole frames, iterations 0 .. n-1, as many as fit the time budget (at least one)
+        iterations = int(max(1, min(args.steps, args.cpu_seconds / max(per_row * height, 1e-9))))
         tc = time.perf_counter()
-        ref.render(0, rect=(0, y0, width, y0 + rows))
+        for it in range(iterations):
+            ref.render(it, threads=threads)
         cpu_s = time.perf_counter() - tc
-        cpu_img = ref.getOutputBufferHost()[y0:y0 + rows]
-        # same sample on the GPU for a free parity check of the benchmarked path
+        cpu_img = ref.getOutputBufferHost()
+        # the same iterations on the GPU: a free parity check of the benchmarked path on the full-size frame
         dev.setOutputDevicePointer(0, 0)
-        dev.render(0)
+        for it in range(iterations):
+            dev.render(it)
         dev.synchronizeStream()
-        gpu_img = dev.getOutputBufferHost()[y0:y0 + rows]
+        gpu_img = dev.getOutputBufferHost()
         result["cpu_baseline"] = {
-            "value": width * rows / cpu_s / 1.0e6,
+            "value": width * height * iterations / cpu_s / 1.0e6,
             "unit": "Msamples/s",
-            "cores": 1,
+            "cores": threads,
             "kind": "port",
-            "sample": f"oracle (oracle/liboracle.so, single thread, own BVH) on iteration 0 of rows {y0}..{y0 + rows - 1} of the {width}x{height} frame = {width * rows} samples in {cpu_s:.1f} s",
-            "host_cores_available": os.cpu_count(),
+            "sample": f"oracle (oracle/liboracle.so, {threads} host threads over rows, own BVH): iterations 0..{iterations - 1} of the {width}x{height} frame = {width * height * iterations} samples in {cpu_s:.1f} s",
+            "host_cores_available": allowed,
             "sample_bit_identical_to_gpu": bool(np.array_equal(cpu_img.view(np.uint32), gpu_img.view(np.uint32))),
         }
 

@@ -134,12 +134,16 @@ class Oracle:
         self._chk(self.lib.orc_get_launch_width(self._h, C.byref(w)))
         return w.value
 
-    def render(self, iterationIndex, rect=None):
-        if rect is None:
+    def render(self, iterationIndex, rect=None, threads=1):
+        """One iteration over the frame or a pixel rectangle; threads > 1 spreads the rows over host threads (same image)."""
+        if rect is None and threads <= 1:
             self._chk(self.lib.orc_render(self._h, C.c_uint(int(iterationIndex))))
-        else:
-            x0, y0, x1, y1 = rect
+            return
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, self.launchWidth, self.state.resolution[1])
+        if threads <= 1:
             self._chk(self.lib.orc_render_rect(self._h, C.c_uint(int(iterationIndex)), int(x0), int(y0), int(x1), int(y1)))
+        else:
+            self._chk(self.lib.orc_render_rect_threads(self._h, C.c_uint(int(iterationIndex)), int(x0), int(y0), int(x1), int(y1), int(threads)))
 
     def getOutputBufferHost(self):
         h, w = self.state.resolution[1], self.launchWidth

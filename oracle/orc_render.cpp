@@ -10,6 +10,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <cmath>
 
 namespace orc {
@@ -24,6 +27,22 @@ struct Oracle
   int  launchWidth = 1;
   uint64_t radianceRays = 0, shadowRays = 0, samples = 0;
 };
+
+struct RayTally { uint64_t radiance = 0, shadow = 0, samples = 0; };
+static RayTally& rayTally() { static thread_local RayTally t; return t; }
+static std::mutex g_tallyMutex;
+
+// Adds this thread's tallies to the handle's totals (end of a render call / of a worker thread).
+static void mergeTallies(Oracle& o)
+{
+  std::lock_guard<std::mutex> lock(g_tallyMutex);
+  RayTally& r = rayTally();
+  o.radianceRays += r.radiance; o.shadowRays += r.shadow; o.samples += r.samples;
+  r = RayTally();
+  TraceCounters& t = traceTally();
+  o.scene.counters.rays += t.rays; o.scene.counters.boxTests += t.boxTests; o.scene.counters.triTests += t.triTests;
+  t = TraceCounters();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Hit context ≙ what the OptiX intrinsics hand to the hit programs.
@@ -80,7 +99,7 @@ static const unsigned int SHADOW_FORK = 0x53484457u; // 'SHDW'
 
 static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const float3& dir, float tmin, float tmax)
 {
-  o.radianceRays++;
+  rayTally().radiance++;
   float lo = tmin;
   for (;;)
   {
@@ -95,7 +114,7 @@ static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const fl
 
 static bool traceShadow(Oracle& o, PerRayData* prd, const float3& org, const float3& dir, float tmin, float tmax)
 {
-  o.shadowRays++;
+  rayTally().shadow++;
   bool anyCutout = false;
   for (const MaterialDefinition& m : o.sys.materialDefinitions)
     if (m.textureCutout != 0) { anyCutout = true; break; }
@@ -392,7 +411,7 @@ static void raygenPathTracer(Oracle& o, unsigned int lx, unsigned int ly)
   const unsigned int index = tiled ? (ly * (unsigned int) o.launchWidth + lx) : (ly * (unsigned int) sysData.resolution.x + launchColumn);
 
   float3 radiance = integrator(o, prd, o.captureFirstHits ? &o.firstHits[index] : nullptr);
-  o.samples++;
+  rayTally().samples++;
 
   if (!(std::isnan(radiance.x) || std::isnan(radiance.y) || std::isnan(radiance.z)))
   {
@@ -676,6 +695,32 @@ int orc_render_rect(OrcHandle o, unsigned int iterationIndex, int x0, int y0, in
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x)
       raygenPathTracer(*o, (unsigned int) x, (unsigned int) y);
+  mergeTallies(*o);
+  return 0;
+}
+
+// Same rows on `threads` host threads (pixels are independent; each thread takes whole rows from a shared counter).
+// For the CPU baseline of bench.py; the image is the one the single-threaded call produces.
+int orc_render_rect_threads(OrcHandle o, unsigned int iterationIndex, int x0, int y0, int x1, int y1, int threads)
+{
+  if (o->sys.cameraDefinitions.empty() || o->sys.materialDefinitions.empty()) { g_error = "orc_render: cameras/materials missing"; return 4; }
+  if (o->captureFirstHits || threads <= 1) return orc_render_rect(o, iterationIndex, x0, y0, x1, y1);
+  o->sys.iterationIndex = (int) iterationIndex;
+  x0 = std::max(x0, 0); y0 = std::max(y0, 0);
+  x1 = std::min(x1, o->launchWidth); y1 = std::min(y1, o->sys.resolution.y);
+  std::atomic<int> nextRow(y0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+  {
+    pool.emplace_back([&]()
+    {
+      for (int y = nextRow.fetch_add(1); y < y1; y = nextRow.fetch_add(1))
+        for (int x = x0; x < x1; ++x)
+          raygenPathTracer(*o, (unsigned int) x, (unsigned int) y);
+      mergeTallies(*o);
+    });
+  }
+  for (std::thread& t : pool) t.join();
   return 0;
 }
 

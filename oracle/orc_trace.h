@@ -38,6 +38,9 @@ struct TraceCounters
   uint64_t rays = 0, boxTests = 0, triTests = 0;
 };
 
+// Per-thread tally of the counters above (orc_render_rect_threads runs rows on several threads).
+inline TraceCounters& traceTally() { static thread_local TraceCounters t{}; return t; }
+
 struct BvhNode // oracle-private layout, not the device layout
 {
   float lo[3], hi[3];
@@ -171,7 +174,7 @@ public:
   std::vector<Geometry> geometries;
   std::vector<Instance> instances;
   bool useBvh = true;
-  mutable TraceCounters counters;
+  mutable TraceCounters counters; // totals; the hot paths tally into traceTally() (thread local) and the render entry points merge
 
   int addGeometry(const TriangleAttributes* attr, size_t numAttr, const unsigned int* idx, size_t numIdx)
   {
@@ -215,7 +218,7 @@ public:
   Hit trace(const float3& origin, const float3& direction, float tmin, float tmax, bool anyHit) const
   {
     Hit best; best.t = tmax; best.beta = best.gamma = 0.0f; best.instance = -1; best.primitive = -1;
-    counters.rays++;
+    traceTally().rays++;
     for (int ii = 0; ii < (int) instances.size(); ++ii)
     {
       const Instance& inst = instances[ii];
@@ -238,7 +241,7 @@ public:
 private:
   void test(const Geometry& g, int ii, int p, const WoopRay& wr, float tmin, Hit& best) const
   {
-    counters.triTests++;
+    traceTally().triTests++;
     const unsigned int i0 = g.indices[3 * p], i1 = g.indices[3 * p + 1], i2 = g.indices[3 * p + 2];
     float t, b, c;
     // tmax passed as +inf-like bound; the commit rule below implements "t < best, ties to the smaller id".
@@ -251,7 +254,7 @@ private:
   // Conservative slab test: true when [tnear, tfar] may overlap (tmin, tbest].
   bool slab(const float lo[3], const float hi[3], const float3& o, const float3& d, float tmin, float tbest) const
   {
-    counters.boxTests++;
+    traceTally().boxTests++;
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
     float tn = tmin, tf = tbest;
     for (int k = 0; k < 3; ++k)
