@@ -773,6 +773,7 @@ int orc_trace_rays(OrcHandle o, const float* rays, size_t numRays, int anyHit, f
       ids[2 * i] = h.instance; ids[2 * i + 1] = h.primitive;
     }
   }
+  mergeTallies(*o);
   return 0;
 }
 

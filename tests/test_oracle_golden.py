@@ -114,3 +114,19 @@ def test_bvh_mode_equals_brute_force_on_random_rays(twk, orc):
     assert np.array_equal(a[1], b[1])
     hit = a[1][:, 0] >= 0
     assert np.array_equal(_bits(a[0][hit]), _bits(b[0][hit]))
+
+
+def test_threaded_render_is_the_same_render(twk, orc):
+    """orc_render_rect_threads (bench.py's CPU baseline): rows on several host threads give the image and the ray
+    tallies of the single-threaded call."""
+    from conftest import load_app
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (96, 54))
+    out = []
+    for threads in (1, 5):
+        ref = orc.Oracle(miss=app.info.miss)
+        ref.loadApplication(app)
+        for it in range(2):
+            ref.render(it, threads=threads)
+        out.append((ref.getOutputBufferHost(), ref.counters()))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert out[0][1] == out[1][1] and out[0][1]["samples"] == 2 * 96 * 54
