@@ -401,8 +401,8 @@ static int flushPending(TwkDevice dev)
   HIP_TRY(hipMemsetAsync(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2), dev->stream));
 
   const int traceGrid = traceGridBlocks(dev);
-  int shadeGrid = (p.numPaths + 511) / 512; // shadeKernel blocks are 512 threads (TWK_SHADE_BLOCK)
-  if (shadeGrid > dev->numCUs * 4) shadeGrid = dev->numCUs * 4;
+  int shadeGrid = (p.numPaths + TWK_SHADE_BLOCK - 1) / TWK_SHADE_BLOCK;
+  if (shadeGrid > dev->numCUs * (2048 / TWK_SHADE_BLOCK)) shadeGrid = dev->numCUs * (2048 / TWK_SHADE_BLOCK); // two rounds of resident blocks
 
   // Bounces [0, wavefrontDepth) run as per-depth trace/shade launches over compacted queues; the remaining bounces
   // of every surviving path run inside one persistent tail kernel (tail_kernel.hip).

@@ -176,6 +176,9 @@ struct LaunchParams
 #endif
 #define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
 #define TWK_TRACE_BLOCK       256
+#ifndef TWK_SHADE_BLOCK
+#define TWK_SHADE_BLOCK       256  // threads per shadeKernel block: queue appends are aggregated per block. Measured (ms/step of shade): 128 → 0.48 (atomics), 256 → 0.33, 512 → 0.34 (waves wait at the block's barriers for its slowest wave), 1024 → 0.37
+#endif
 #define TWK_TRACE_TICKET      64   // queue slots per wave ticket (coarser tickets starve the chip: a launch holds only ~18 groups per wave)
 
 } // namespace twk

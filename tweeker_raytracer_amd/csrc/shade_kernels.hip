@@ -98,14 +98,13 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 // One thread per ray of queue (depth & 1): shadePath(), then append the continuation ray to queue ((depth + 1) & 1)
 // and the shadow ray (with the pending contribution) to the shadow queue.
 //
-// Queue appends are aggregated per BLOCK: every wave counts its appenders with a ballot, the block sums the wave
-// counts through LDS and one lane issues ONE returning atomic per queue per block iteration. With one atomic per
+// Queue appends are aggregated per BLOCK (TWK_SHADE_BLOCK threads): every wave counts its appenders with a ballot, the
+// block sums the wave counts through LDS and one lane issues ONE returning atomic per queue per block iteration. With one atomic per
 // wave the two counter words saw ~110 k returning atomics per step and the kernel sat in s_waitcnt for 87 % of its
 // wave-cycles (a single word sustains ~90 atomics/us on this chip: MI355X_MICROARCH "dequeue").
 #ifndef TWK_SHADE_WAVES
 #define TWK_SHADE_WAVES 4
 #endif
-#define TWK_SHADE_BLOCK 512
 
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(LaunchParams p, int depth)
 {
