@@ -294,6 +294,9 @@ int twk_app_get_instance(TwkApp app, int idInstance, int* idGeometry, float tran
 /* Runs the reference's init sequence on a device: setState, initCameras, initLights, initMaterials,
  * initScene (Application.cpp:303,328-332). */
 int twk_app_init_device(TwkApp app, TwkDevice dev);
+/* ≙ the text Application::saveSystemDescription writes (Application.cpp:1300-1345): the current settings in the
+ * loader's grammar. Two-call protocol: out == NULL returns the length (without the terminator) in *length. */
+int twk_app_system_description(TwkApp app, char* out, size_t capacity, size_t* length);
 /* Tonemapper settings of the system description ("gamma", "colorBalance", "whitePoint", "burnHighlights",
  * "crushBlacks", "saturation", "brightness", Application.cpp:1244-1292). */
 int twk_app_get_tonemapper(TwkApp app, TwkTonemapper* tm);

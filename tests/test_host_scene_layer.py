@@ -118,3 +118,27 @@ def test_tile_map_is_a_partition(twk):
     assert twk.launch_width(3840, 8, 8) == 480  # C5
     with pytest.raises(twk.TwkError):
         twk.tile_column(0, 0, (6, 8), 2, 0)
+
+
+def test_system_description_round_trip(twk):
+    """≙ Application::saveSystemDescription (Application.cpp:1300-1345): keys in the reference's order, and loading the
+    text back gives the same settings (numbers go through operator<<: six significant digits, like the reference)."""
+    from conftest import scene_path
+    scene = open(scene_path("scene_rtigo3_cornell_box_c1.txt")).read()
+    src = ("strategy 2\ndevicesMask 15\ninterop 1\npresent 1\nresolution 640 360\ntileSize 16 8\nsamplesSqrt 3\nmiss 2\nenvMap sky.hdr\n"
+           "envRotation 0.25\nclockFactor 250\nlight 2\npathLengths 3 7\nepsilonFactor 800\nlensShader 1\ncenter 0.5 1.25 -2\n"
+           "camera 0.7 0.45 50 4.5\nprefixScreenshot ./out/shot\ngamma 2.2\ncolorBalance 1 0.9 0.8\nwhitePoint 1.5\nburnHighlights 0.8\n"
+           "crushBlacks 0.2\nsaturation 1.2\nbrightness 0.7\n")
+    app = twk.Application(system_text=src, scene_text=scene)
+    text = app.systemDescription()
+    assert text == src
+    again = twk.Application(system_text=text, scene_text=scene)
+    a, b = app.info, again.info
+    for name, _ in a._fields_:
+        va, vb = getattr(a, name), getattr(b, name)
+        assert (list(va) == list(vb)) if hasattr(va, "__len__") else (va == vb), name
+    ta, tb = app.tonemapper, again.tonemapper
+    assert bytes(ta) == bytes(tb) and again.environment == "sky.hdr"
+    # defaults: no envMap line, neutral tonemapper
+    text = twk.Application(system_text="", scene_text=scene).systemDescription()
+    assert "envMap" not in text and text.splitlines()[0] == "strategy 0" and "gamma 1\n" in text and text.endswith("brightness 1\n")

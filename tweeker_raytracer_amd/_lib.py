@@ -93,7 +93,7 @@ SYMBOLS = [
     "twk_app_create", "twk_app_create_from_strings", "twk_app_destroy", "twk_app_info", "twk_app_set_resolution",
     "twk_app_get_state", "twk_app_get_cameras", "twk_app_get_lights", "twk_app_get_materials",
     "twk_app_get_geometry_sizes", "twk_app_get_geometry", "twk_app_get_instance", "twk_app_init_device",
-    "twk_app_get_tonemapper", "twk_app_screenshot_path", "twk_load_image", "twk_app_get_environment",
+    "twk_app_system_description", "twk_app_get_tonemapper", "twk_app_screenshot_path", "twk_load_image", "twk_app_get_environment",
     "twk_write_png_rgb8", "twk_write_hdr_rgba32f",
     "twk_mesh_plane", "twk_mesh_box", "twk_mesh_sphere", "twk_mesh_torus", "twk_mesh_parallelogram",
     "twk_camera_frustum", "twk_tile_column", "twk_launch_width", "twk_parse_tokens",

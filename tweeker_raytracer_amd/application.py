@@ -84,6 +84,14 @@ class Application:
     def instances(self):
         return [self.instance(i) for i in range(self.info.numInstances)]
 
+    def systemDescription(self):
+        """≙ Application::saveSystemDescription: the current settings as a system description text."""
+        n = C.c_size_t(0)
+        L.check(L.lib.twk_app_system_description(self._h, None, C.c_size_t(0), C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        L.check(L.lib.twk_app_system_description(self._h, buf, C.c_size_t(len(buf)), None))
+        return buf.value.decode()
+
     @property
     def tonemapper(self):
         """Tonemapper settings of the system description (Application.cpp:1244-1292)."""

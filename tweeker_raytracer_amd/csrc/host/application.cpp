@@ -56,8 +56,8 @@ bool Application::loadSystemDescription(const std::string& text, std::string& er
       if (ok) { if (0 <= i[0] && i[0] < 4) strategy = i[0]; else warnings.push_back("invalid renderer strategy, using 0"); }
     }
     else if (key == "devicesMask") { ok = readInt(parser, devicesMask); }
-    else if (key == "interop")     { ok = readInt(parser, i[0]); } // no OpenGL interop in this build
-    else if (key == "present")     { ok = readInt(parser, i[0]); }
+    else if (key == "interop")     { ok = readInt(parser, interop); } // kept for saveSystemDescription; no OpenGL interop in this build
+    else if (key == "present")     { ok = readInt(parser, i[0]); if (ok) present = (i[0] != 0); }
     else if (key == "resolution")
     {
       ok = readInt(parser, i[0]) && readInt(parser, i[1]);
@@ -118,6 +118,39 @@ bool Application::loadSystemDescription(const std::string& text, std::string& er
 
   camera.setResolution(resolution[0], resolution[1]); // Application.cpp:207
   return true;
+}
+
+// ≙ Application::saveSystemDescription (Application.cpp:1300-1345): the current settings in the grammar the loader
+// reads, same keys in the same order, numbers through operator<< like the reference.
+std::string Application::systemDescription() const
+{
+  std::ostringstream d;
+  d << "strategy " << strategy << std::endl;
+  d << "devicesMask " << devicesMask << std::endl;
+  d << "interop " << interop << std::endl;
+  d << "present " << (present ? "1" : "0") << std::endl;
+  d << "resolution " << resolution[0] << " " << resolution[1] << std::endl;
+  d << "tileSize " << tileSize[0] << " " << tileSize[1] << std::endl;
+  d << "samplesSqrt " << samplesSqrt << std::endl;
+  d << "miss " << miss << std::endl;
+  if (!environment.empty()) d << "envMap " << environment << std::endl;
+  d << "envRotation " << envRotation << std::endl;
+  d << "clockFactor " << clockFactor << std::endl;
+  d << "light " << light << std::endl;
+  d << "pathLengths " << pathLengths[0] << " " << pathLengths[1] << std::endl;
+  d << "epsilonFactor " << epsilonFactor << std::endl;
+  d << "lensShader " << lensShader << std::endl;
+  d << "center " << camera.center[0] << " " << camera.center[1] << " " << camera.center[2] << std::endl;
+  d << "camera " << camera.phi << " " << camera.theta << " " << camera.fov << " " << camera.distance << std::endl;
+  if (!prefixScreenshot.empty()) d << "prefixScreenshot " << prefixScreenshot << std::endl;
+  d << "gamma " << tonemapper.gamma << std::endl;
+  d << "colorBalance " << tonemapper.colorBalance[0] << " " << tonemapper.colorBalance[1] << " " << tonemapper.colorBalance[2] << std::endl;
+  d << "whitePoint " << tonemapper.whitePoint << std::endl;
+  d << "burnHighlights " << tonemapper.burnHighlights << std::endl;
+  d << "crushBlacks " << tonemapper.crushBlacks << std::endl;
+  d << "saturation " << tonemapper.saturation << std::endl;
+  d << "brightness " << tonemapper.brightness << std::endl;
+  return d.str();
 }
 
 void Application::setResolution(int w, int h)

@@ -70,11 +70,14 @@ public:
   bool buildScene(const std::string& sceneText, std::string& error);
 
   void setResolution(int w, int h);
+  std::string systemDescription() const;
   TwkDeviceState deviceState() const;
 
   // system options (Application.cpp:55-75,105-120 defaults)
   int   strategy      = 0;
   int   devicesMask   = 255;
+  int   interop       = 0;
+  bool  present       = false;
   int   light         = 0;
   int   miss          = 1;
   int   lensShader    = 0;

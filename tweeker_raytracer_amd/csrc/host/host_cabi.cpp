@@ -168,6 +168,17 @@ int twk_app_init_device(TwkApp app, TwkDevice dev)
   return twk_build(dev);
 }
 
+int twk_app_system_description(TwkApp app, char* out, size_t capacity, size_t* length)
+{
+  if (!app) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_system_description: NULL argument");
+  const std::string s = app->app.systemDescription();
+  if (length) *length = s.size();
+  if (!out) return TWK_SUCCESS;
+  if (s.size() + 1 > capacity) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_system_description: buffer too small");
+  memcpy(out, s.c_str(), s.size() + 1);
+  return TWK_SUCCESS;
+}
+
 int twk_app_get_tonemapper(TwkApp app, TwkTonemapper* tm)
 {
   if (!app || !tm) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_tonemapper: NULL argument");
