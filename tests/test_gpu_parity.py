@@ -245,3 +245,30 @@ def test_tail_kernel_option_does_not_change_the_image(twk, monkeypatch):
         imgs.append(dev.getOutputBufferHost())
         dev.close()
     assert np.array_equal(_bits(imgs[0]), _bits(imgs[1])) and np.array_equal(_bits(imgs[0]), _bits(imgs[2]))
+
+
+def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
+    """A pass whose path streams exceed the memory it may take (here a 6 MiB budget: the real limit is the device's
+    HBM) is cut in halves until it fits; the image is the one of the undivided pass, and a frame that does not fit
+    even for one iteration reports out-of-memory instead of crashing."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (96, 54))
+    imgs = []
+    for budget in (None, "6"):  # 96*54 px * 344 B = 1.7 MiB per iteration: 16 iterations need 27 MiB, 3 fit in 6 MiB
+        if budget is None:
+            monkeypatch.delenv("TWK_STREAM_BUDGET_MB", raising=False)
+        else:
+            monkeypatch.setenv("TWK_STREAM_BUDGET_MB", budget)
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        app.initDevice(dev)
+        for it in range(16):
+            dev.render(it)
+        imgs.append(dev.getOutputBufferHost())
+        dev.close()
+    assert np.array_equal(_bits(imgs[0]), _bits(imgs[1]))
+    monkeypatch.setenv("TWK_STREAM_BUDGET_MB", "1")
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    dev.render(0)
+    with pytest.raises(twk.TwkError, match="TWK_STREAM_BUDGET_MB"):
+        dev.synchronizeStream()
+    dev.close()

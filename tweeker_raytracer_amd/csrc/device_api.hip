@@ -118,6 +118,7 @@ struct TwkDevice_t
   // Deferred launches: twk_launch only records the iteration; consecutive iterations are rendered together as one
   // wavefront pass of up to batchMax samples per pixel when the batch is full or anything observes the device.
   int   batchMax = 64;
+  size_t streamBudgetBytes = 0; // TWK_STREAM_BUDGET_MB: cap on the path streams of one pass (0 = device memory is the limit)
   unsigned int pendingFirst = 0;
   int   pendingCount = 0;
   int   allocatedPaths = 0;
@@ -258,6 +259,8 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     // float4 streams: rayOrg[2], rayDir[2], hitRecord, shadowOrg, shadowDir, shadowPending, throughput, radiance, volumeStack[4] = 14
     // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]
     const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
+    if (dev->streamBudgetBytes != 0 && bytes > dev->streamBudgetBytes)
+      return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "path streams of " + std::to_string(bytes >> 20) + " MiB exceed TWK_STREAM_BUDGET_MB");
     HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
     dev->allocatedPaths = numPaths;
   }
@@ -385,17 +388,45 @@ static void calculateSphericalCDF(const float* rgba, unsigned int width, unsigne
   else                  { for (unsigned int y = 1; y <= height; ++y) cdfV[y] = float(y) / float(height); }
 }
 
-// Runs the recorded iterations [pendingFirst, pendingFirst + pendingCount) as one wavefront pass.
+static int renderPass(TwkDevice dev, unsigned int firstIteration, int count);
+
 static int flushPending(TwkDevice dev)
 {
-  int rc;
-  if ((rc = ensureStreams(dev, dev->pendingCount))) return rc;
+  // The streams of a pass take 344 bytes per pixel and iteration. When they do not fit in device memory the pass is
+  // cut in halves until they do (the image does not depend on how iterations are grouped) and the handle keeps the
+  // smaller limit; only an allocation failure for a single iteration is reported.
+  unsigned int first = dev->pendingFirst;
+  int left = dev->pendingCount;
+  dev->pendingCount = 0;
+  while (left > 0)
+  {
+    int count = (left < dev->batchMax) ? left : dev->batchMax;
+    if (count < 1) count = 1;
+    for (;;)
+    {
+      const int rc = ensureStreams(dev, count);
+      if (rc == TWK_SUCCESS) break;
+      (void) hipGetLastError(); // the failed allocation must not surface again at the next launch check
+      if (rc != TWK_ERROR_OUT_OF_MEMORY || count == 1) return rc;
+      count = (count + 1) / 2;
+      dev->batchMax = count;
+    }
+    const int rc = renderPass(dev, first, count);
+    if (rc) return rc;
+    first += (unsigned int) count;
+    left -= count;
+  }
+  return TWK_SUCCESS;
+}
+
+// Runs iterations [firstIteration, firstIteration + count) as one wavefront pass; the streams are allocated.
+static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
+{
   refreshParams(dev);
   LaunchParams& p = dev->params;
-  p.iterationIndex = dev->pendingFirst;
-  p.batchCount = dev->pendingCount;
+  p.iterationIndex = firstIteration;
+  p.batchCount = count;
   p.numPaths = p.numPixels * p.batchCount;
-  dev->pendingCount = 0;
 
   const int maxDepth = dev->state.pathLengths[1];
   HIP_TRY(hipMemsetAsync(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2), dev->stream));
@@ -479,6 +510,7 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
   }
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
+  if (const char* e = getenv("TWK_STREAM_BUDGET_MB")) { const long long mb = atoll(e); dev->streamBudgetBytes = (mb > 0) ? (size_t) mb << 20 : 0; }
   if (const char* e = getenv("TWK_BATCH")) { const int b = atoi(e); dev->batchMax = (b < 1) ? 1 : ((b > 64) ? 64 : b); }
   *out = dev;
   return TWK_SUCCESS;
