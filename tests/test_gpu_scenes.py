@@ -222,3 +222,56 @@ def test_compositor_kernel(twk):
                     expect[y, px] = src[d, y, x]
     assert np.array_equal(got, expect) and (got >= 0).all()
     dev.close()
+
+
+def test_update_camera_light_material_between_launches(twk, orc):
+    """≙ Device::updateCamera / updateLight / updateMaterial (Device.cpp:1083-1168), the interactive edit path: after
+    an update the caller restarts at iteration 0 (Raytracer.cpp:331-338). Launches recorded BEFORE an update render
+    with the old values (the update flushes them); the restarted accumulation equals a fresh device — and the oracle —
+    set up with the new values."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (128, 72))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    for it in range(3):
+        dev.render(it)                       # still pending when the updates arrive
+    before = None
+
+    mats = app.materials
+    mats[2].albedo[0], mats[2].albedo[1], mats[2].albedo[2] = 0.2, 0.4, 0.9   # repaint a wall
+    mats[6].indexBSDF = 3                                                        # mirror sphere → GGX
+    mats[6].roughness[0], mats[6].roughness[1] = 0.3, 0.15
+    cam = twk.camera_frustum((0.1, 1.0, 0.0), 0.7, 0.55, 50.0, 3.2, 128 / 72)
+    (light,) = app.lights
+    light.emission[0], light.emission[1], light.emission[2] = 14.0, 11.0, 8.0
+
+    dev.updateMaterial(2, mats[2])
+    before = dev.getOutputBufferHost()       # the three old iterations were rendered with the OLD scene
+    dev.updateMaterial(6, mats[6])
+    dev.updateCamera(0, cam)
+    dev.updateLight(0, light)
+    for it in range(3):
+        dev.render(it)                       # restart: iteration 0 overwrites
+    after = dev.getOutputBufferHost()
+
+    old = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(old)
+    for it in range(3):
+        old.render(it)
+    assert np.array_equal(_bits(before), _bits(old.getOutputBufferHost()))
+    old.close()
+
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    ref.initMaterials(mats)
+    ref.initCameras([cam])
+    ref.initLights([light])
+    for it in range(3):
+        ref.render(it)
+    cpu = ref.getOutputBufferHost()
+    assert not np.array_equal(_bits(before), _bits(after))
+    assert np.array_equal(_bits(after), _bits(cpu))
+    with pytest.raises(twk.TwkError):
+        dev.updateMaterial(99, mats[2])
+    with pytest.raises(twk.TwkError):
+        dev.updateCamera(5, cam)
+    dev.close()
