@@ -275,3 +275,33 @@ def test_update_camera_light_material_between_launches(twk, orc):
     with pytest.raises(twk.TwkError):
         dev.updateCamera(5, cam)
     dev.close()
+
+
+def test_scene_replacement_output_pointer_and_stream_probe(twk, orc):
+    """twk_clear_scene + a second initScene on the same handle (≙ Device::initScene called again, Device.cpp:1058-1080)
+    renders like a fresh handle; twk_get_output_device_pointer names the accumulation buffer; the stream probe used
+    for the measured-bandwidth line of DESIGN.md returns a sane figure."""
+    first = load_app(twk, "system_rtigo3_geometry.txt", "scene_rtigo3_geometry.txt", (96, 54))
+    second = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (96, 54))
+    dev = twk.Device(ordinal=0, miss=second.info.miss)
+    first.initDevice(dev)
+    dev.render(0)
+    dev.synchronizeStream()
+    second.initDevice(dev)                    # clears the first scene, uploads and builds the second
+    for it in range(2):
+        dev.render(it)
+    img = dev.getOutputBufferHost()
+    ref = orc.Oracle(miss=second.info.miss)
+    ref.loadApplication(second)
+    for it in range(2):
+        ref.render(it)
+    assert np.array_equal(_bits(img), _bits(ref.getOutputBufferHost()))
+    ptr, nbytes = dev.outputDevicePointer()
+    assert ptr != 0 and nbytes == 96 * 54 * 16
+    dev.clearScene()
+    with pytest.raises(twk.TwkError):         # nothing to render until the scene is built again
+        dev.render(0)
+        dev.synchronizeStream()
+    gbps = dev.streamPeakGBps(1 << 28, 3)
+    assert 500.0 < gbps < 20000.0
+    dev.close()
