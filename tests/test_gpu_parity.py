@@ -268,7 +268,7 @@ def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
     monkeypatch.setenv("TWK_STREAM_BUDGET_MB", "1")
     dev = twk.Device(ordinal=0, miss=app.info.miss)
     app.initDevice(dev)
-    dev.render(0)
     with pytest.raises(twk.TwkError, match="TWK_STREAM_BUDGET_MB"):
+        dev.render(0)                # recorded; reported by the call that runs the pass
         dev.synchronizeStream()
     dev.close()
