@@ -1,46 +1,54 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the HIP wavefront path tracer on the Cornell box (BASELINE.json metric).
 
-A step is one launch of the hot path (≙ one optixLaunch, reference DeviceSingleGPU.cpp:164) = one sample
-per pixel over the whole frame; K steps = K progressive iterations (reference Application::benchmark,
-Application.cpp:491-513: the timer brackets the launch loop and the final device sync; scene/BVH build and
-image write-out are outside). Default K = 64 = the 64 spp of config C2.
+A step is one launch of the hot path (≙ one optixLaunch, reference DeviceSingleGPU.cpp:164) = one sample per pixel
+over the whole frame; K steps = K progressive iterations (reference Application::benchmark, Application.cpp:491-513:
+the timer brackets the launch loop and the final device sync; scene/BVH build and image write-out are outside).
+Default K = 64 = the 64 spp of config C2.
 
-N = 1: config C2, Cornell box 1920x1080, full BSDF set, scenes/*cornell_box.txt.
-N > 1 (torchrun, one rank per GPU): weak scaling — the frame keeps the 16:9 camera but grows to N x 2,073,600
-pixels, tile-interleaved over the ranks exactly like the reference's distribute() (raygeneration.cu:152-164);
-every rank accumulates its launchWidth x H share locally for all K steps, then ONE gather to rank 0 over RCCL
-and one compositor kernel assemble the image inside the timed region.
+N = 1: config C2, Cornell box 1920x1080, full BSDF set (scenes/system_rtigo3_cornell_box.txt).
+N > 1 (torch.distributed.run, one rank per GPU): config C5 — the FIXED 3840x2160 Cornell frame
+(scenes/system_rtigo3_cornell_box_c5.txt) tile-interleaved over the ranks exactly like the reference's distribute()
+(raygeneration.cu:152-164; launchWidth = roundup(ceil(W / N), 8), DeviceMultiGPULocalCopy.cpp:84-97): STRONG scaling.
+Every rank accumulates its launchWidth x H share locally for all K steps with no communication; then ONE gather to
+rank 0 over RCCL and one compositor kernel assemble the image, inside the timed region. After the timed region rank
+0 renders the same iterations of the whole frame on its own GPU and the composed image must equal it bit for bit
+(`composite_bit_identical_to_single_device`, CRC-32 of both images in the line). `--weak` keeps round 1's mode
+(16:9 frame grown to N x 2,073,600 pixels).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import math
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_SPEC_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; the denominator used below is the copy rate MEASURED on the box
 
-# Algorithmic bytes of the traversal kernel (DESIGN.md "Roofline model"): fixed record sizes, cache hits do not reduce them.
+# Algorithmic bytes of the traversal kernel, SURVEY.md §8(d)'s record table (cache hits do not reduce them):
 B_RAY_FIXED = 48      # 32 B ray record in + 16 B hit record out (shadow rays: 32 B ray + 16 B pending contribution)
-B_NODE = 128          # one 4-ary wide node (four child boxes + references, two 64-byte halves)
-B_TRIANGLE = 48       # one triangle slot (three float4)
-B_INSTANCE = 64       # world-to-object rows + BVH root of the instance record
+B_NODE = 128          # one 4-ary wide-node visit = two levels of §8(d)'s 64-byte binary nodes fetched at once
+B_TRIANGLE = 48       # one Woop triangle slot (three float4)
+B_INSTANCE = 64       # instance entry (two-level scenes only): world-to-object rows + BVH root, what an IAS leaf hands an OptiX traversal
+# 16-byte lane loads the kernel issues per unit (what the divergent-gather ceiling prices)
+L_RAY, L_NODE, L_TRIANGLE, L_INSTANCE = 2, 8, 3, 4
 
 
-def frame_for(n_gpus, base=(1920, 1080)):
+def weak_frame_for(n_gpus, base=(1920, 1080)):
     if n_gpus == 1:
         return base
     s = math.sqrt(n_gpus)
-    w = int(round(base[0] * s / 8.0)) * 8
-    h = int(round(base[1] * s / 8.0)) * 8
-    return (w, h)
+    return (int(round(base[0] * s / 8.0)) * 8, int(round(base[1] * s / 8.0)) * 8)
+
+
+def crc(img):
+    return "%08x" % (zlib.crc32(img.tobytes()) & 0xFFFFFFFF)
 
 
 def main():
@@ -48,10 +56,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--system", default=os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box.txt"))
+    ap.add_argument("--system", default=None, help="system description (default: C2 at N = 1, C5 at N > 1)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene_rtigo3_cornell_box.txt"))
+    ap.add_argument("--batch", type=int, default=64, help="iterations rendered together per wavefront pass (twk_set_launch_batch, 1..64)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: round 1's weak-scaling frame (N x 2,073,600 pixels) instead of the fixed C5 frame")
+    ap.add_argument("--c5", action="store_true", help="N = 1: render the C5 frame (3840x2160) instead of C2 — the one-GPU point of the strong-scaling curve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-composite-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the oracle sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a share of 16 cores)")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -83,16 +95,20 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     device = torch.device("cuda", local_rank)
-    width, height = frame_for(n_gpus)
-
-    app = twk.Application(args.system, args.scene)
-    app.setResolution(width, height)
+    c5 = (n_gpus > 1 and not args.weak) or (n_gpus == 1 and args.c5)
+    system = args.system or os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box_c5.txt" if c5 else "system_rtigo3_cornell_box.txt")
+    app = twk.Application(system, args.scene)
+    if n_gpus > 1 and args.weak:
+        app.setResolution(*weak_frame_for(n_gpus))
     info = app.info
+    width, height = info.resolution[0], info.resolution[1]
+
     dev = twk.Device(ordinal=local_rank, index=rank, count=n_gpus, miss=info.miss)
     app.initDevice(dev, distribution=1 if n_gpus > 1 else 0)
-    # path streams for the largest pass the timed loop will issue (twk_launch batches up to 64 iterations per pass):
-    # allocated here, not inside the timed region
-    dev.reserveLaunchBatch(min(64, max(1, args.steps)))
+    batch = max(1, min(64, args.batch))
+    dev.setLaunchBatch(batch)
+    # path streams for the largest pass the timed loop will issue: allocated here, not inside the timed region
+    dev.reserveLaunchBatch(min(batch, max(1, args.steps)))
     lw = dev.launchWidth
 
     # The accumulation buffer is a torch tensor so RCCL can send it without a copy.
@@ -109,23 +125,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def check_composite():
-        """N > 1 only, after the timed region: the composed image must equal a single-device render of the frame."""
-        single = twk.Device(ordinal=local_rank, miss=info.miss)
-        app.initDevice(single)
-        single.setLaunchBatch(max(1, 64 // n_gpus))  # the frame is n_gpus times a rank's share: same stream memory as a rank
-        for it in range(0, args.warmup + args.steps):  # the accumulator keeps the warm-up iterations, like the ranks' buffers
-            single.render(it)
-        ref_img = single.getOutputBufferHost()
-        single.close()
-        return bool(np.array_equal(ref_img.view(np.uint32), composed.cpu().numpy().view(np.uint32)))
+    exchange = {"ms": 0.0}
 
     def run_steps(first, count, finish=True):
         for it in range(first, first + count):
             dev.render(it)
         dev.synchronizeStream()
         if dist is not None and finish:
-            # the one exchange step of the path: gather the packed tile buffers, scatter into the image
+            # the one exchange step of the path: gather the packed tile buffers, scatter them into the image
+            tx = time.perf_counter()
             if args.rehearse_gloo:
                 host = accum.cpu()
                 parts = [torch.empty_like(host) for _ in range(n_gpus)] if rank == 0 else None
@@ -138,6 +146,7 @@ def main():
                 torch.cuda.synchronize(device)
                 dev.compositor(gathered.data_ptr(), composed.data_ptr())
                 dev.synchronizeStream()
+            exchange["ms"] = (time.perf_counter() - tx) * 1.0e3
 
     run_steps(0, args.warmup)
     barrier()
@@ -150,11 +159,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    composite_ok = None
-    if dist is not None and rank == 0 and os.environ.get("TWK_BENCH_CHECK_COMPOSITE", "1" if args.rehearse_gloo else "0") == "1":
-        composite_ok = check_composite()
+    # ---- N > 1: the composed image against a single-device render of the same iterations (outside the timed region)
+    composite = None
+    if dist is not None and rank == 0 and not args.no_composite_check and os.environ.get("TWK_BENCH_CHECK_COMPOSITE", "1") == "1":
+        single = twk.Device(ordinal=local_rank, miss=info.miss)
+        app.initDevice(single)
+        single.setLaunchBatch(max(1, batch // n_gpus))  # the frame is n_gpus times a rank's share: same stream memory as a rank
+        for it in range(0, args.warmup + args.steps):   # the accumulator keeps the warm-up iterations, like the ranks' buffers
+            single.render(it)
+        ref_img = single.getOutputBufferHost()
+        single.close()
+        comp_img = composed.cpu().numpy()
+        composite = {"ok": bool(np.array_equal(ref_img.view(np.uint32), comp_img.view(np.uint32))),
+                     "crc_composed": crc(comp_img), "crc_single": crc(ref_img)}
 
     samples = float(width) * float(height) * float(args.steps)
+    if c5:
+        workload = "C5: Cornell box (scene_rtigo3_cornell_box.txt, full BSDF set, 64,096 triangles, 8 instances), fixed frame tiled over the ranks"
+    elif n_gpus > 1:
+        workload = "C2 grown for weak scaling: Cornell box, 16:9 frame of N x 2,073,600 pixels"
+    else:
+        workload = "C2: Cornell box (scene_rtigo3_cornell_box.txt: Lambert + GGX wall + mirror + glass spheres, 64,096 triangles, 8 instances)"
     result = {
         "metric": "Msamples/s (paths x spp x res / s), Cornell box 1920x1080",
         "value": samples / elapsed / 1.0e6,
@@ -164,22 +189,44 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1.0e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if (n_gpus > 1 and args.weak) else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "C2: Cornell box (scene_rtigo3_cornell_box.txt: Lambert + GGX wall + mirror + glass spheres, 64,096 triangles, 8 instances), "
-                        f"{width}x{height}, {args.steps} spp progressive (1 spp per step), pathLengths {info.pathLengths[0]} {info.pathLengths[1]}, light 1, miss 0",
+            "workload": workload + f", {width}x{height}, {args.steps} spp progressive (1 spp per step), pathLengths {info.pathLengths[0]} {info.pathLengths[1]}, light 1, miss 0",
             "resolution": [width, height],
             "pixels_per_gpu_per_step": lw * height,
-            "parallelism": "single GPU" if n_gpus == 1 else f"tile-interleaved pixels over {n_gpus} ranks (8x8 tiles), one RCCL gather + compositor at the end",
+            "launch_width": lw,
+            "batch_depth": min(batch, max(1, args.steps)),
+            "batch_note": "twk_launch is deferred: up to batch_depth consecutive iterations are rendered as ONE wavefront pass (bit-identical image); batch1_Msamples_per_s is the rate at one pass per iteration",
+            "parallelism": "single GPU" if n_gpus == 1 else f"tile-interleaved pixels over {n_gpus} ranks (8x8 tiles, distribute()), local accumulation, one RCCL gather + one compositor launch at the end",
         },
     }
-    if composite_ok is not None:
-        result["config"]["composite_bit_identical_to_single_device"] = composite_ok
+    if dist is not None:
+        result["config"]["gather_bytes_per_rank"] = lw * height * 16
+        result["config"]["gather_bytes_into_root"] = lw * height * 16 * (n_gpus - 1)
+        result["config"]["gather_plus_compositor_ms"] = exchange["ms"]  # rank 0, inside the timed region
+    if composite is not None:
+        result["config"]["composite_bit_identical_to_single_device"] = composite["ok"]
+        result["config"]["crc32_composed"] = composite["crc_composed"]
+        result["config"]["crc32_single_device"] = composite["crc_single"]
     if args.rehearse_gloo:
         result["config"]["rehearsal"] = "gloo, all ranks on GPU 0 — NOT a scaling measurement"
+
+    # ---- one pass per iteration (what a caller that synchronises after every launch gets, DeviceSingleGPU.cpp:147)
+    if rank == 0 and n_gpus == 1 and not args.no_roofline:
+        dev.setLaunchBatch(1)
+        k1 = max(2, min(args.steps, 16))
+        for it in range(2):
+            dev.render(it)
+        dev.synchronizeStream()
+        tb = time.perf_counter()
+        for it in range(args.warmup, args.warmup + k1):
+            dev.render(it)
+        dev.synchronizeStream()
+        result["config"]["batch1_Msamples_per_s"] = width * height * k1 / (time.perf_counter() - tb) / 1.0e6
+        dev.setLaunchBatch(batch)
 
     # ---- roofline of the dominant kernel (traversal), measured on the same steps --------------------
     if not args.no_roofline and rank == 0:
@@ -193,39 +240,69 @@ def main():
         run_steps(args.warmup, args.steps, finish=False)
         st = dev.statsGet(reset=True)
         dev.statsEnable(False)
+        stream_peak = dev.streamPeakGBps(1 << 30, 10)       # float4 copy, read + write bytes, measured on this box
+        gather_peak = dev.gatherPeak(32 << 20)              # G lane-loads/s (16 B each) from a scene-sized, cache-resident table
         rays = st["radianceRays"] + st["shadowRays"]
-        algo_bytes = (B_RAY_FIXED * rays + B_NODE * st["nodesVisited"] + B_TRIANGLE * st["trianglesTested"] + B_INSTANCE * st["instancesEntered"])
-        trace_ms, trace_launches = prof["trace"]["ms"], prof["trace"]["launches"]
-        achieved = algo_bytes / (trace_ms * 1.0e-3) / 1.0e9 if trace_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_trace_hbm_traffic.json")
+        algo_bytes = B_RAY_FIXED * rays + B_NODE * st["nodesVisited"] + B_TRIANGLE * st["trianglesTested"] + B_INSTANCE * st["instancesEntered"]
+        lane_loads = L_RAY * rays + L_NODE * st["nodesVisited"] + L_TRIANGLE * st["trianglesTested"] + L_INSTANCE * st["instancesEntered"]
+        trace_ms, trace_launches = prof["trace"]["ms"], max(1, prof["trace"]["launches"])
+        trace_s = max(trace_ms * 1.0e-3, 1e-12)
+        algo_gbps = algo_bytes / trace_s / 1.0e9
+        gather_gbps = lane_loads * 16 / trace_s / 1.0e9
+        # HBM-side bytes come from rocprofv3 --pmc passes (tools/pmc_collect.sh), which cannot run inside this process:
+        # carried from the committed summary ONLY when it was taken on this very configuration, else null
+        traffic, traffic_note = None, "no PMC summary for this configuration (tools/pmc_collect.sh + tools/pmc_traffic.py write profiles/r02_trace_hbm_traffic.json)"
+        pmc_path = os.path.join(ROOT, "profiles", "r02_trace_hbm_traffic.json")
         if os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    pmc = json.load(f)
+                same = (pmc.get("steps") == args.steps and pmc.get("batch_depth") == result["config"]["batch_depth"]
+                        and pmc.get("resolution") == [width, height] and n_gpus == 1)
+                if same:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+                    traffic_note = f"carried from {os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this kernel, same steps / batch / resolution); not measured in this run"
+                else:
+                    traffic_note = f"{os.path.basename(pmc_path)} was taken at steps {pmc.get('steps')}, batch {pmc.get('batch_depth')}, {pmc.get('resolution')}: not this run's launch size, so not reported"
             except Exception:
-                traffic = None
+                pass
+        fractions = {
+            "algorithmic_bytes_vs_stream_peak": algo_gbps / stream_peak,
+            "hbm_side_bytes_vs_stream_peak": (traffic / (trace_s / trace_launches) / 1.0e9 / stream_peak) if traffic else None,
+            "lane_loads_vs_gather_ceiling": (lane_loads / trace_s / 1.0e9) / gather_peak,
+        }
+        # The scene (19 MB) lives in L2 / Infinity Cache: the algorithmic bytes are cache-level throughput and may exceed
+        # what HBM could stream. The memory-side ceiling that does apply is the divergent-gather rate of the vector
+        # memory path (one lane address per clock and CU), so that is the roofline reported; all three are in `fractions`.
         result["roofline"] = {
-            "kernel": "twk::traceKernel<false, false>",
+            "kernel": "twk::traceKernel<false, false, %s>" % ("true" if st["instancesEntered"] else "false"),
             "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
+            "achieved": gather_gbps,
+            "peak": gather_peak * 16.0,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
+            "frac": gather_gbps / (gather_peak * 16.0),
             "traffic": traffic,
-            "note": "achieved counts every node / triangle / instance fetch at full record size (SURVEY 8d: cache hits do not reduce them); the 19 MB scene is served from L2 / Infinity Cache, so frac can exceed 1 - the HBM-side bytes are `traffic` (PMC); what bounds the kernel: DESIGN.md 4.1",
-            "algorithmic_bytes_per_launch": algo_bytes / max(1, trace_launches),
-            "avg_launch_ms": trace_ms / max(1, trace_launches),
+            "traffic_note": traffic_note,
+            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued (2 per ray, 8 per wide node, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel beyond memory (vector issue at partial lane occupancy): DESIGN.md 4.1",
+            "fractions": fractions,
+            "stream_peak_gbps_measured": stream_peak,
+            "hbm_spec_gbps": HBM_SPEC_GBPS,
+            "gather_peak_glaneloads_per_s_measured": gather_peak,
+            "algorithmic_gbps": algo_gbps,
+            "algorithmic_bytes_per_launch": algo_bytes / trace_launches,
+            "algorithmic_record_table": {"ray_in_hit_out": B_RAY_FIXED, "wide_node_visit(2 x 64 B binary levels)": B_NODE, "triangle": B_TRIANGLE, "instance_entry": B_INSTANCE},
+            "avg_launch_ms": trace_ms / trace_launches,
             "launches": trace_launches,
             "rays_per_step": rays / args.steps,
             "nodes_per_ray": st["nodesVisited"] / max(1, rays),
             "triangles_per_ray": st["trianglesTested"] / max(1, rays),
+            "instance_entries_per_ray": st["instancesEntered"] / max(1, rays),
             "lane_occupancy": {"node_step": st["nodesVisited"] / max(1, 64 * st["nodeWaveSteps"]),
                                "triangle_test": st["trianglesTested"] / max(1, 64 * st["triangleWaveSteps"]),
-                               "node_wave_steps_per_launch": st["nodeWaveSteps"] / max(1, trace_launches),
-                               "triangle_wave_steps_per_launch": st["triangleWaveSteps"] / max(1, trace_launches),
-                               "leaf_wave_steps_per_launch": st["leafWaveSteps"] / max(1, trace_launches)},
-            "Mrays_per_s": rays / (trace_ms * 1.0e-3) / 1.0e6 if trace_ms > 0 else 0.0,
+                               "node_wave_steps_per_launch": st["nodeWaveSteps"] / trace_launches,
+                               "triangle_wave_steps_per_launch": st["triangleWaveSteps"] / trace_launches,
+                               "leaf_wave_steps_per_launch": st["leafWaveSteps"] / trace_launches},
+            "Mrays_per_s": rays / trace_s / 1.0e6,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         }
 

@@ -118,6 +118,18 @@ typedef struct TwkDeviceState
   float clockFactor;     /* accepted, unused (USE_TIME_VIEW is 0 in the reference build) */
 } TwkDeviceState;
 
+/* Flattening (build option of twk_build, ≙ the accelBuildOptions of Device.cpp:1383-1389): an instance is FLATTENED
+ * when its geometry has at most `maxTriangles` triangles (walls, light quads) or is referenced by at most
+ * `maxReferences` instances (instancing saves no memory worth a per-ray instance entry). Flattened instances are
+ * intersected in WORLD space: their vertices are transformed once at twk_build (row-major 3x4 object-to-world,
+ * m0*x + m1*y + m2*z + m3 in fp32, as transformPoint closesthit.cu:88-98 evaluates it) and tested against the
+ * untransformed ray, all in one world-space BVH; every other instance is entered through the top level with the ray
+ * taken through the inverse transform (≙ IAS→GAS descent, Device.cpp:1427-1445). t, beta, gamma name the same
+ * quantities either way; which one applies is part of the traversal contract the CPU oracle restates
+ * (oracle/orc_trace.h), so both sides take the same policy. (0, 0) = pure two-level. */
+#define TWK_FLATTEN_TRIANGLES  4
+#define TWK_FLATTEN_REFERENCES 2
+
 /* Texture slots ≙ the three hard-wired textures of Device::initTextures (Device.cpp:911-942). */
 enum { TWK_TEXTURE_ALBEDO = 0, TWK_TEXTURE_CUTOUT = 1, TWK_TEXTURE_ENVIRONMENT = 2 };
 
@@ -189,6 +201,8 @@ int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12],
                      int idMaterial, int idLight, int* idInstance);                    /* ≙ createInstance Device.cpp:1427-1445 + hit record :1492-1532 */
 int twk_build(TwkDevice dev);                                                          /* ≙ createTLAS + createHitGroupRecords Device.cpp:1448-1532 */
 int twk_clear_scene(TwkDevice dev);
+/* Flattening policy of the next twk_build (defaults TWK_FLATTEN_TRIANGLES, TWK_FLATTEN_REFERENCES; see there). */
+int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences);
 
 /* ≙ Device*::render(iterationIndex, buffer) → optixLaunch(pipeline, stream, d_sys, 192, &sbt, W, H, 1)
  * (DeviceSingleGPU.cpp:104-182; multi-GPU: DeviceMultiGPULocalCopy.cpp:104-190).
@@ -246,6 +260,10 @@ int twk_profile_get(TwkDevice dev, float msPerKernelClass[TWK_KERNEL_COUNT], int
 int twk_stats_enable(TwkDevice dev, int enable);     /* counting kernel variants (not for timed runs) */
 int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset);
 int twk_stream_peak_gbps(TwkDevice dev, size_t bytes, int repeats, float* gbps); /* float4 copy kernel */
+/* Divergent-gather ceiling: every lane of every wave chases its own chain of 128-byte lines through a table of
+ * tableBytes and reads each line as eight 16-byte loads (the access pattern of a wide-node fetch); returns giga
+ * lane-loads (16 B each) per second. With a table the size of the scene this is the memory-side ceiling of traversal. */
+int twk_gather_peak(TwkDevice dev, size_t tableBytes, float* gigaLaneLoadsPerSecond);
 
 /* ---- debugging / parity taps (stage-level SoA read-back after one launch) ------------------ */
 /* First-bounce hit record per pixel of the last launch: t, beta, gamma, instance, primitive.

@@ -122,6 +122,10 @@ class Oracle:
         for (g, t, m, l) in app.instances:
             self.addInstance(g, t, m, l)
 
+    def setFlattenPolicy(self, maxTriangles, maxReferences):
+        """≙ Device.setFlattenPolicy: which instances are intersected in world space (include/tweeker_hip.h)."""
+        self._chk(self.lib.orc_set_flatten_policy(self._h, int(maxTriangles), int(maxReferences)))
+
     def setTraceMode(self, use_bvh):
         self._chk(self.lib.orc_set_trace_mode(self._h, int(bool(use_bvh))))
 
@@ -144,6 +148,13 @@ class Oracle:
             self._chk(self.lib.orc_render_rect(self._h, C.c_uint(int(iterationIndex)), int(x0), int(y0), int(x1), int(y1)))
         else:
             self._chk(self.lib.orc_render_rect_threads(self._h, C.c_uint(int(iterationIndex)), int(x0), int(y0), int(x1), int(y1), int(threads)))
+
+    def debugPath(self, iterationIndex, x, y, capacity=256):
+        """Rays the sample (x, y, iteration) traces, in call order: [n, 9] = o.xyz, tmin, d.xyz, tmax, kind (0 radiance, 1 shadow)."""
+        rays = np.zeros((capacity, 9), np.float32)
+        n = C.c_int(0)
+        self._chk(self.lib.orc_debug_path(self._h, C.c_uint(int(iterationIndex)), int(x), int(y), _f(rays), int(capacity), C.byref(n)))
+        return rays[:min(n.value, capacity)]
 
     def getOutputBufferHost(self):
         h, w = self.state.resolution[1], self.launchWidth

@@ -97,9 +97,19 @@ static inline bool cutoutIgnores(const Oracle& o, const HitContext& hc, unsigned
 //     versions either).
 static const unsigned int SHADOW_FORK = 0x53484457u; // 'SHDW'
 
+// Debug tap (orc_debug_path): the rays one pixel's sample traces, in call order: o.xyz, tmin, d.xyz, tmax, kind (0 radiance, 1 shadow).
+static thread_local std::vector<float>* g_pathLog = nullptr;
+static inline void logRay(const float3& org, const float3& dir, float tmin, float tmax, float kind)
+{
+  if (!g_pathLog) return;
+  const float r[9] = {org.x, org.y, org.z, tmin, dir.x, dir.y, dir.z, tmax, kind};
+  g_pathLog->insert(g_pathLog->end(), r, r + 9);
+}
+
 static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const float3& dir, float tmin, float tmax)
 {
   rayTally().radiance++;
+  logRay(org, dir, tmin, tmax, 0.0f);
   float lo = tmin;
   for (;;)
   {
@@ -115,6 +125,7 @@ static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const fl
 static bool traceShadow(Oracle& o, PerRayData* prd, const float3& org, const float3& dir, float tmin, float tmax)
 {
   rayTally().shadow++;
+  logRay(org, dir, tmin, tmax, 1.0f);
   bool anyCutout = false;
   for (const MaterialDefinition& m : o.sys.materialDefinitions)
     if (m.textureCutout != 0) { anyCutout = true; break; }
@@ -679,6 +690,7 @@ int orc_clear_scene(OrcHandle o) { o->scene.clear(); return 0; }
 
 // 0 = brute force over all triangles (the definition), 1 = oracle BVH (same results, faster)
 int orc_set_trace_mode(OrcHandle o, int useBvh) { o->scene.useBvh = (useBvh != 0); return 0; }
+int orc_set_flatten_policy(OrcHandle o, int maxTriangles, int maxReferences) { o->scene.setFlattenPolicy(maxTriangles, maxReferences); return 0; } // ≙ twk_set_flatten_policy
 int orc_capture_first_hits(OrcHandle o, int enable) { o->captureFirstHits = (enable != 0); return 0; }
 
 int orc_get_launch_width(OrcHandle o, int* w) { *w = o->launchWidth; return 0; }
@@ -689,6 +701,7 @@ int orc_get_launch_width(OrcHandle o, int* w) { *w = o->launchWidth; return 0; }
 int orc_render_rect(OrcHandle o, unsigned int iterationIndex, int x0, int y0, int x1, int y1)
 {
   if (o->sys.cameraDefinitions.empty() || o->sys.materialDefinitions.empty()) { g_error = "orc_render: cameras/materials missing"; return 4; }
+  o->scene.prepare();
   o->sys.iterationIndex = (int) iterationIndex;
   x0 = std::max(x0, 0); y0 = std::max(y0, 0);
   x1 = std::min(x1, o->launchWidth); y1 = std::min(y1, o->sys.resolution.y);
@@ -705,6 +718,7 @@ int orc_render_rect_threads(OrcHandle o, unsigned int iterationIndex, int x0, in
 {
   if (o->sys.cameraDefinitions.empty() || o->sys.materialDefinitions.empty()) { g_error = "orc_render: cameras/materials missing"; return 4; }
   if (o->captureFirstHits || threads <= 1) return orc_render_rect(o, iterationIndex, x0, y0, x1, y1);
+  o->scene.prepare();
   o->sys.iterationIndex = (int) iterationIndex;
   x0 = std::max(x0, 0); y0 = std::max(y0, 0);
   x1 = std::min(x1, o->launchWidth); y1 = std::min(y1, o->sys.resolution.y);
@@ -721,6 +735,25 @@ int orc_render_rect_threads(OrcHandle o, unsigned int iterationIndex, int x0, in
     });
   }
   for (std::thread& t : pool) t.join();
+  return 0;
+}
+
+// Debug tap: the rays the sample (x, y, iterationIndex) traces — 9 floats each (o.xyz, tmin, d.xyz, tmax, kind) —
+// without touching the accumulation buffer's other pixels. Returns the number of rays in *numRays.
+int orc_debug_path(OrcHandle o, unsigned int iterationIndex, int x, int y, float* rays, int capacity, int* numRays)
+{
+  o->scene.prepare();
+  o->sys.iterationIndex = (int) iterationIndex;
+  std::vector<float> log;
+  const std::vector<float4> saved = o->output;
+  g_pathLog = &log;
+  raygenPathTracer(*o, (unsigned int) x, (unsigned int) y);
+  g_pathLog = nullptr;
+  o->output = saved;
+  mergeTallies(*o);
+  const int n = (int) (log.size() / 9);
+  *numRays = n;
+  for (int i = 0; i < n && i < capacity; ++i) memcpy(rays + 9 * i, log.data() + 9 * i, sizeof(float) * 9);
   return 0;
 }
 
@@ -758,6 +791,7 @@ int orc_get_counters(OrcHandle o, uint64_t out[6])
 // optixTrace contract on arbitrary rays (8 floats: o.xyz, tmin, d.xyz, tmax).
 int orc_trace_rays(OrcHandle o, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids)
 {
+  o->scene.prepare();
   for (size_t i = 0; i < numRays; ++i)
   {
     const float* r = rays + 8 * i;

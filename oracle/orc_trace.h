@@ -10,6 +10,12 @@
 //   * geometry: float3 positions at stride 48 B, uint3 indices — Device.cpp:1362-1381
 //   * instance: row-major 3x4 object→world, ray taken to object space, t preserved — Device.cpp:1434
 //   * barycentrics (beta, gamma) weight vertex 1 and 2 — shaders/closesthit.cu:142-147
+//   * flattened instances (include/tweeker_hip.h twk_set_flatten_policy: geometry with at most maxTriangles
+//     triangles, or referenced by at most maxReferences instances): intersected in WORLD space — the vertices are
+//     taken to world space once (row-major 3x4, m0*x + m1*y + m2*z + m3 in fp32, as transformPoint
+//     closesthit.cu:88-98 evaluates it) and tested against the untransformed ray. t, beta, gamma are the same
+//     quantities as in object space (t is preserved by the affine map); which space the closed OptiX traversal rounds
+//     in is not observable from the reference, so the policy is part of this build's definition of the contract.
 // The triangle test is the published watertight algorithm of Woop, Benthin, Wald (JCGT 2013) in
 // single precision with the double-precision fallback on zero edge functions, every operation
 // spelled out so that the HIP kernel can be compared bit for bit. Ties in t resolve to the smaller
@@ -20,6 +26,7 @@
 // tests/test_oracle_trace.py checks that).
 #pragma once
 #include "orc_types.h"
+#include "../include/tweeker_hip.h" // TWK_FLATTEN_TRIANGLES
 #include <algorithm>
 #include <cfloat>
 
@@ -65,6 +72,7 @@ struct Instance
   int   material;
   int   light;
   float lo[3], hi[3]; // world AABB of the transformed vertices
+  int   worldGeometry = -1; // flattened instance: index into Scene::worldGeometries (its vertices in world space + a BVH over them)
 };
 
 // Inverse of a row-major 3x4 affine matrix, evaluated in double and rounded once.
@@ -173,6 +181,9 @@ class Scene
 public:
   std::vector<Geometry> geometries;
   std::vector<Instance> instances;
+  std::vector<Geometry> worldGeometries; // one per flattened instance, see prepare()
+  int  flattenMaxTriangles = TWK_FLATTEN_TRIANGLES, flattenMaxReferences = TWK_FLATTEN_REFERENCES;
+  bool dirty = true;
   bool useBvh = true;
   mutable TraceCounters counters; // totals; the hot paths tally into traceTally() (thread local) and the render entry points merge
 
@@ -209,20 +220,61 @@ public:
       inst.lo[k] -= e; inst.hi[k] += e;
     }
     instances.push_back(inst);
+    dirty = true;
     return (int) instances.size() - 1;
   }
 
-  void clear() { geometries.clear(); instances.clear(); }
+  void clear() { geometries.clear(); instances.clear(); worldGeometries.clear(); dirty = true; }
+
+  void setFlattenPolicy(int maxTriangles, int maxReferences) { flattenMaxTriangles = maxTriangles; flattenMaxReferences = maxReferences; dirty = true; }
+
+  // Decides which instances are flattened (twk_set_flatten_policy's rule) and gives each of them its world-space
+  // vertices. Called by the entry points before anything is traced.
+  void prepare()
+  {
+    if (!dirty) return;
+    worldGeometries.clear();
+    std::vector<int> references(geometries.size(), 0);
+    for (const Instance& inst : instances) references[inst.geometry]++;
+    for (Instance& inst : instances)
+    {
+      const Geometry& g = geometries[inst.geometry];
+      inst.worldGeometry = -1;
+      if ((int) (g.indices.size() / 3) > flattenMaxTriangles && references[inst.geometry] > flattenMaxReferences) continue;
+      Geometry w;
+      w.attributes = g.attributes;
+      w.indices = g.indices;
+      for (TriangleAttributes& a : w.attributes) a.vertex = xfmPoint(inst.objectToWorld, a.vertex);
+      buildBvh(w);
+      inst.worldGeometry = (int) worldGeometries.size();
+      worldGeometries.push_back(std::move(w));
+    }
+    dirty = false;
+  }
 
   // Closest hit (anyHit == false) or first-found occlusion (anyHit == true).
   Hit trace(const float3& origin, const float3& direction, float tmin, float tmax, bool anyHit) const
   {
     Hit best; best.t = tmax; best.beta = best.gamma = 0.0f; best.instance = -1; best.primitive = -1;
     traceTally().rays++;
+    WoopRay wrWorld; woopSetup(origin, direction, wrWorld);
     for (int ii = 0; ii < (int) instances.size(); ++ii)
     {
       const Instance& inst = instances[ii];
       if (useBvh && !slab(inst.lo, inst.hi, origin, direction, tmin, best.t)) continue;
+      if (inst.worldGeometry >= 0)
+      {
+        // flattened instance: world-space vertices against the untransformed ray (see the header)
+        const Geometry& w = worldGeometries[inst.worldGeometry];
+        if (useBvh) traverse(w, ii, wrWorld, origin, direction, tmin, anyHit, best);
+        else
+        {
+          const int numPrims = (int) (w.indices.size() / 3);
+          for (int p = 0; p < numPrims; ++p) test(w, ii, p, wrWorld, tmin, best);
+        }
+        if (anyHit && best.instance >= 0) return best;
+        continue;
+      }
       const float3 o = xfmPoint(inst.worldToObject, origin);
       const float3 d = xfmVector(inst.worldToObject, direction);
       WoopRay wr; woopSetup(o, d, wr);
@@ -312,6 +364,19 @@ private:
         for (int k = 0; k < 3; ++k) { lo[3 * p + k] = std::min(lo[3 * p + k], c[k]); hi[3 * p + k] = std::max(hi[3 * p + k], c[k]); }
       }
       for (int k = 0; k < 3; ++k) ce[3 * p + k] = 0.5f * (lo[3 * p + k] + hi[3 * p + k]);
+      // The triangle test's t carries an absolute error that scales with the triangle's size and coordinates, not
+      // with t (a ray that starts 2e-4 above a 16-unit floor triangle gets t off by 3e-7): grow every primitive box on
+      // all axes by 2^-17 of (largest coordinate magnitude + diagonal) so that this BVH never culls what brute force
+      // — the definition — would report.
+      float m = 0.0f, d2 = 0.0f;
+      for (int k = 0; k < 3; ++k)
+      {
+        m = std::max(m, std::max(fabsf(lo[3 * p + k]), fabsf(hi[3 * p + k])));
+        const float d = hi[3 * p + k] - lo[3 * p + k];
+        d2 += d * d;
+      }
+      const float e = 7.6293945e-6f * (m + sqrtf(d2)) + 1.0e-30f;
+      for (int k = 0; k < 3; ++k) { lo[3 * p + k] -= e; hi[3 * p + k] += e; }
     }
     g.nodes.reserve(2 * numPrims);
     struct Job { int node, first, count; };

@@ -13,18 +13,38 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_compose_the_single_device_image():
+def _rehearse(ranks, extra=()):
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    port = 29600 + (os.getpid() % 300)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3",
-           "--rehearse-gloo", "--no-roofline"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    port = 29600 + (os.getpid() % 300) + ranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "8", "--warmup", "3",
+           "--batch", "8", "--rehearse-gloo", "--no-roofline", *extra]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["steps"] == 8 and res["scaling"] == "weak"
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_compose_the_single_device_image_of_c5(ranks):
+    """Default N > 1 mode = C5: the fixed 3840x2160 Cornell frame, strong scaling, launchWidth = roundup(ceil(W / N), 8)
+    (DeviceMultiGPULocalCopy.cpp:84-97); the composite check runs by default and its CRCs are in the line."""
+    res = _rehearse(ranks)
+    assert res["n_gpus"] == ranks and res["steps"] == 8 and res["scaling"] == "strong"
+    cfg = res["config"]
+    assert cfg["resolution"] == [3840, 2160]
+    lw = -(-3840 // ranks)
+    lw = (lw + 7) & ~7
+    assert cfg["launch_width"] == lw and cfg["pixels_per_gpu_per_step"] == lw * 2160
+    assert cfg["gather_bytes_per_rank"] == lw * 2160 * 16 and cfg["gather_plus_compositor_ms"] > 0
+    assert cfg["composite_bit_identical_to_single_device"] is True
+    assert cfg["crc32_composed"] == cfg["crc32_single_device"]
+
+
+def test_two_ranks_weak_mode():
+    res = _rehearse(2, ("--weak",))
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
     assert res["config"]["composite_bit_identical_to_single_device"] is True
     w, h = res["config"]["resolution"]
     assert abs(w * h - 2 * 1920 * 1080) < 0.01 * 2 * 1920 * 1080 and w % 8 == 0 and h % 8 == 0

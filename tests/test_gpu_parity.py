@@ -228,6 +228,32 @@ def test_error_paths(twk):
     dev.close()
 
 
+def test_fewer_materials_or_lights_than_the_built_scene_uses_is_refused(twk):
+    """A built scene's instances hold material / light indices; re-initialising either table with fewer entries would
+    leave them dangling (an out-of-bounds read in the shade kernel). Refused with INVALID_STATE, state unchanged."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (32, 32))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    dev.render(0)
+    before = dev.getOutputBufferHost().copy()
+    mats, lights = app.materials, app.lights
+    assert len(mats) > 1 and len(lights) == 1
+    with pytest.raises(twk.TwkError) as e:
+        dev.initMaterials(mats[:1])
+    assert e.value.code == 4  # TWK_ERROR_INVALID_STATE
+    with pytest.raises(twk.TwkError) as e:
+        dev.initLights([])
+    assert e.value.code == 4  # TWK_ERROR_INVALID_STATE
+    dev.initMaterials(mats)      # same count: fine
+    dev.initLights(lights)
+    dev.render(0)
+    assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(before))
+    dev.clearScene()             # after the scene is gone the tables may shrink
+    dev.initLights([])
+    dev.initMaterials(mats[:1])
+    dev.close()
+
+
 def test_tail_kernel_option_does_not_change_the_image(twk, monkeypatch):
     """TWK_TAIL_DEPTH=n (off by default): bounces >= n of every surviving path run in one persistent kernel
     instead of per-depth launches. Same device functions, same bits."""

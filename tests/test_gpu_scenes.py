@@ -305,3 +305,39 @@ def test_scene_replacement_output_pointer_and_stream_probe(twk, orc):
     gbps = dev.streamPeakGBps(1 << 28, 3)
     assert 500.0 < gbps < 20000.0
     dev.close()
+
+
+@pytest.mark.parametrize("policy", [(0, 0), (4, 2), (1 << 30, 1 << 30)])
+@pytest.mark.parametrize("system,scene,res,iters", [
+    ("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (128, 72), 2),
+    ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", (96, 54), 2),
+])
+def test_flatten_policy_two_level_soup_and_mixed(twk, orc, system, scene, res, iters, policy):
+    """twk_set_flatten_policy (include/tweeker_hip.h): (0, 0) pure two-level — every instance entered with a transformed
+    ray —, the default (walls / light quads and rarely referenced geometries in the world-space soup, spliced into the
+    top level next to the entered instances), and everything flattened (one single-level BVH). The oracle takes the
+    same policy; images bit-identical in all three, and the instance-entry counter tells which path ran."""
+    app = load_app(twk, system, scene, res)
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    dev.setFlattenPolicy(*policy)
+    app.initDevice(dev)
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    ref.setFlattenPolicy(*policy)
+    dev.statsEnable(True)
+    dev.statsGet(reset=True)
+    for it in range(iters):
+        dev.render(it)
+        ref.render(it)
+    gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+    st = dev.statsGet(reset=True)
+    mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+    assert mism == 0, f"policy {policy}: {mism} pixels differ, max |diff| {np.abs(gpu - cpu).max()}"
+    entered = st["instancesEntered"]
+    if policy == (0, 0):
+        assert entered > 0
+    if policy[0] > 4 or "cornell" in scene and policy != (0, 0):
+        assert entered == 0, "every instance of this scene is flattened under this policy: nothing may be entered"
+    if "instances" in scene and policy == (4, 2):
+        assert entered > 0, "the grid's shared meshes stay instanced under the default policy"
+    dev.close()

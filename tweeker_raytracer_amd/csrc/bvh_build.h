@@ -13,28 +13,35 @@ public:
   // Bottom level over the triangles of one geometry. Writes max(1, numTriangles - 1) nodes at
   // outNodes[0..] whose inner references are nodeBase-relative absolutes and numTriangles triangle
   // slots at outTriangles[3 * triangleBase ..] (+ the 128-byte shading records at outShadeTriangles[TWK_SHADE_RECORD * triangleBase ..]). rootBounds receives the (padded) object-space box.
+  // soup != nullptr: the world-space soup of the flattened instances instead — numTriangles descriptors (bvh_build.hip
+  // soupVertices), attributes / indices are the SHARED arrays, leaves carry TWK_LEAF_WORLD, rootBounds is a world box.
   hipError_t buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
-                            BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6]);
+                            BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6],
+                            const int4* soup = nullptr, const DevInstance* instances = nullptr);
+  // Descriptors of one flattened instance: its geometry's triangles 0..count-1 become soup primitives first..first+count-1.
+  void soupDescriptors(hipStream_t stream, int4* soup, int first, int count, int instance, int attributeBase, int indexBase);
 
-  // Top level over instance boxes given on the host. Leaf reference = ~instance index.
-  hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase);
+  // Top level over boxes given on the host. Child reference of primitive k = ~hostLeafPayload[k]: an instance index
+  // gives a leaf, ~(root node of the soup) splices the soup's tree in as a subtree.
+  hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, const int* hostLeafPayload, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase);
 
   void release();
-  void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 8) ? 8 : n); }
+  void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 4) ? 4 : n); } // count - 1 takes two bits of a leaf reference
 
 private:
   hipError_t reserve(int count);
-  hipError_t buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase);
+  hipError_t buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase, int leafFlag);
 
   int m_capacity = 0;
   float4* m_primLo = nullptr; float4* m_primHi = nullptr;
   unsigned long long* m_keysIn = nullptr; unsigned long long* m_keysOut = nullptr;
   int* m_left = nullptr; int* m_right = nullptr; int* m_innerParent = nullptr; int* m_leafParent = nullptr;
   int2* m_range = nullptr;
-  int m_maxLeaf = 2; // triangles per bottom-level leaf (1..8); measured on C2: 1 → 1156, 2 → 1215, 3 → 1172, 4 → 1106 Msamples/s
+  int m_maxLeaf = 2; // triangles per bottom-level leaf (1..4); measured on C2: 1 → 1156, 2 → 1215, 3 → 1172, 4 → 1106 Msamples/s
   unsigned int* m_tickets = nullptr;
   float4* m_nodeLo = nullptr; float4* m_nodeHi = nullptr;
   unsigned int* m_bounds = nullptr;
+  int* m_leafPayload = nullptr; // top level: leaf payload per instance
   void* m_sortTemp = nullptr; size_t m_sortBytes = 0;
 };
 

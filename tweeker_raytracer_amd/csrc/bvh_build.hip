@@ -32,22 +32,48 @@ __global__ void initBoundsKernel(unsigned int* bounds)
   else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;          // max
 }
 
-// Triangle boxes of one geometry. attributes: 12 floats per vertex (position first), indices: 3 per triangle.
+// Soup descriptor of one flattened triangle: x = instance, y = first vertex of its geometry in the shared attribute
+// array, z = first index of the TRIANGLE in the shared index array, w = primitive index inside the geometry.
+// Vertex c of a soup triangle, in world space: the geometry's object-space position through the instance's
+// object-to-world matrix — m0*x + m1*y + m2*z + m3 in fp32, the expression transformPoint (closesthit.cu:88-98) and
+// the oracle evaluate.
+TWK_D void soupVertices(const int4& d, const float* __restrict__ attributes, const unsigned int* __restrict__ indices,
+                        const DevInstance* __restrict__ instances, const float*& a, const float*& b, const float*& c, V3& wa, V3& wb, V3& wc)
+{
+  const unsigned int i0 = indices[d.z], i1 = indices[d.z + 1], i2 = indices[d.z + 2];
+  a = attributes + 12 * ((size_t) d.y + i0);
+  b = attributes + 12 * ((size_t) d.y + i1);
+  c = attributes + 12 * ((size_t) d.y + i2);
+  const float* m = instances[d.x].objectToWorld;
+  wa = transformPoint(m, v3(a[0], a[1], a[2]));
+  wb = transformPoint(m, v3(b[0], b[1], b[2]));
+  wc = transformPoint(m, v3(c[0], c[1], c[2]));
+}
+
+// Triangle boxes of one geometry (object space), or of the world-space soup of the flattened instances (soup != nullptr:
+// attributes / indices are then the shared arrays). attributes: 12 floats per vertex (position first), indices: 3 per triangle.
 __global__ void triangleBoxesKernel(const float* __restrict__ attributes, const unsigned int* __restrict__ indices,
+                                    const int4* __restrict__ soup, const DevInstance* __restrict__ instances,
                                     int count, float4* __restrict__ primLo, float4* __restrict__ primHi, unsigned int* bounds)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const unsigned int i0 = indices[3 * i], i1 = indices[3 * i + 1], i2 = indices[3 * i + 2];
-  const float* a = attributes + 12 * (size_t) i0;
-  const float* b = attributes + 12 * (size_t) i1;
-  const float* c = attributes + 12 * (size_t) i2;
-  float lo[3], hi[3];
-  for (int k = 0; k < 3; ++k)
+  V3 va, vb, vc;
+  if (soup != nullptr)
   {
-    lo[k] = fminf(fminf(a[k], b[k]), c[k]);
-    hi[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+    const float *a, *b, *c;
+    soupVertices(soup[i], attributes, indices, instances, a, b, c, va, vb, vc);
   }
+  else
+  {
+    const unsigned int i0 = indices[3 * i], i1 = indices[3 * i + 1], i2 = indices[3 * i + 2];
+    const float* a = attributes + 12 * (size_t) i0;
+    const float* b = attributes + 12 * (size_t) i1;
+    const float* c = attributes + 12 * (size_t) i2;
+    va = v3(a[0], a[1], a[2]); vb = v3(b[0], b[1], b[2]); vc = v3(c[0], c[1], c[2]);
+  }
+  const float lo[3] = { fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z) };
+  const float hi[3] = { fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z) };
   primLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
   primHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
   for (int k = 0; k < 3; ++k)
@@ -55,6 +81,14 @@ __global__ void triangleBoxesKernel(const float* __restrict__ attributes, const 
     atomicMin(&bounds[k], orderedBits(lo[k]));
     atomicMax(&bounds[3 + k], orderedBits(hi[k]));
   }
+}
+
+// Soup descriptors of one flattened instance: triangle k of its geometry → soup primitive first + k.
+__global__ void soupDescriptorsKernel(int4* __restrict__ soup, int first, int count, int instance, int attributeBase, int indexBase)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  soup[first + k] = make_int4(instance, attributeBase, indexBase + 3 * k, k);
 }
 
 __global__ void boxBoundsKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi, int count, unsigned int* bounds)
@@ -145,14 +179,20 @@ __global__ void radixTreeKernel(const unsigned long long* __restrict__ keys, int
 
 TWK_D void padBox(float4& lo, float4& hi)
 {
-  // The watertight triangle test may accept a ray that misses the exact triangle by a rounding error;
-  // boxes are grown so the conservative slab test never culls such a hit.
-  const float k = 1.9073486e-6f; // 2^-19
-  const float ex = k * (fmaxf(fabsf(lo.x), fabsf(hi.x)) + (hi.x - lo.x)) + 1.0e-30f;
-  const float ey = k * (fmaxf(fabsf(lo.y), fabsf(hi.y)) + (hi.y - lo.y)) + 1.0e-30f;
-  const float ez = k * (fmaxf(fabsf(lo.z), fabsf(hi.z)) + (hi.z - lo.z)) + 1.0e-30f;
-  lo.x -= ex; lo.y -= ey; lo.z -= ez;
-  hi.x += ex; hi.y += ey; hi.z += ez;
+  // The watertight triangle test reports t with an ABSOLUTE error that scales with the triangle's size and with the
+  // magnitude of its coordinates (the edge functions are differences of products of vertex-minus-origin terms), not
+  // with t: a ray that starts 2e-4 above a 16-unit floor triangle gets a t that is off by 3e-7, 1e-3 of its value —
+  // measured: with axis-tight boxes (a flat floor: pad 1e-30 in y) the slab interval [3.52942e-4, 3.52942e-4] was
+  // culled against a current best of 3.52938e-4 although the triangle test would have returned 3.5266e-4. Every
+  // primitive box therefore grows on ALL axes by 2^-17 (128 ulp) of (largest coordinate magnitude + box diagonal):
+  // two orders of magnitude above the observed error, 0.03 % of a 0.03-unit triangle. Errors that scale with the
+  // distance travelled are covered by the relative widening of the slab test itself (trace_device.h).
+  const float k = 7.6293945e-6f; // 2^-17
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
+  const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  const float e = k * (m + sqrtf(dx * dx + dy * dy + dz * dz)) + 1.0e-30f;
+  lo.x -= e; lo.y -= e; lo.z -= e;
+  hi.x += e; hi.y += e; hi.z += e;
 }
 
 TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const float4& lo1, const float4& hi1, int c0, int c1)
@@ -206,17 +246,20 @@ TWK_D void writeWideNode(BvhNode* wide, const WideEntry* e)
 }
 
 // One thread per leaf walks up; the second thread to arrive at an inner node (ticket == 1) owns it.
-// leafMode 0 (triangles): leaf reference = ~(first slot | (count - 1) << 28) with first = leafBase + sorted
+// leafMode 0 (triangles): leaf reference = ~(first slot | (count - 1) << 28 | leafFlag) with first = leafBase + sorted
 // position; a child subtree that covers at most maxLeaf sorted positions is referenced as ONE leaf (its slots are
 // contiguous because the leaves of a radix tree are in key order), which removes the bottom levels of the tree.
-// leafMode 1 (instances): leaf reference = ~(primitive index), never collapsed.
+// leafFlag = TWK_LEAF_WORLD for the world-space soup of the flattened instances (device_types.h), else 0.
+// leafMode 1 (top level): child reference = ~leafPayload[primitive index]: payload = instance index gives a leaf;
+// payload = ~(root node of the soup) gives an INNER reference — the soup's tree becomes a subtree of the top level.
 __global__ void refitKernel(const unsigned long long* __restrict__ keys, int count,
                             const float4* __restrict__ primLo, const float4* __restrict__ primHi,
                             const int* __restrict__ left, const int* __restrict__ right,
                             const int* __restrict__ innerParent, const int* __restrict__ leafParent,
                             const int2* __restrict__ range,
                             unsigned int* __restrict__ tickets, float4* nodeLo, float4* nodeHi,
-                            BvhNode* outNodes, BvhNode* __restrict__ outWide, int nodeBase, int leafMode, int leafBase, int maxLeaf)
+                            BvhNode* outNodes, BvhNode* __restrict__ outWide, int nodeBase, int leafMode, int leafBase, int maxLeaf,
+                            const int* __restrict__ leafPayload, int leafFlag)
 {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= count) return;
@@ -236,25 +279,25 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
     {
       const unsigned int prim = (unsigned int) (keys[~l] & 0xffffffffull);
       lo0 = primLo[prim]; hi0 = primHi[prim]; padBox(lo0, hi0);
-      c0 = (leafMode == 0) ? ~(leafBase + ~l) : ~((int) prim);
+      c0 = (leafMode == 0) ? ~((leafBase + ~l) | leafFlag) : ~leafPayload[prim];
     }
     else
     {
       lo0 = nodeLo[l]; hi0 = nodeHi[l];
       const int2 rg = range[l];
-      c0 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28)) : nodeBase + l;
+      c0 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28) | leafFlag) : nodeBase + l;
     }
     if (r < 0)
     {
       const unsigned int prim = (unsigned int) (keys[~r] & 0xffffffffull);
       lo1 = primLo[prim]; hi1 = primHi[prim]; padBox(lo1, hi1);
-      c1 = (leafMode == 0) ? ~(leafBase + ~r) : ~((int) prim);
+      c1 = (leafMode == 0) ? ~((leafBase + ~r) | leafFlag) : ~leafPayload[prim];
     }
     else
     {
       lo1 = nodeLo[r]; hi1 = nodeHi[r];
       const int2 rg = range[r];
-      c1 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28)) : nodeBase + r;
+      c1 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28) | leafFlag) : nodeBase + r;
     }
     writeNode(&outNodes[node], lo0, hi0, lo1, hi1, c0, c1);
     {
@@ -273,15 +316,17 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
 
 // A single primitive has no inner node: emit one node whose second child can never be hit.
 __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi,
-                                 BvhNode* outNodes, BvhNode* outWide, float4* nodeLo, float4* nodeHi, int leafMode, int leafBase)
+                                 BvhNode* outNodes, BvhNode* outWide, float4* nodeLo, float4* nodeHi, int leafMode, int leafBase,
+                                 const int* __restrict__ leafPayload, int leafFlag)
 {
+  const int leafRef = (leafMode == 0) ? ~(leafBase | leafFlag) : ~leafPayload[0];
   float4 lo = primLo[0], hi = primHi[0];
   padBox(lo, hi);
   const float inf = __uint_as_float(0x7f800000u);
   const float4 elo = make_float4(inf, inf, inf, 0.0f), ehi = make_float4(inf, inf, inf, 0.0f); // never hit, see emptyEntry()
-  writeNode(&outNodes[0], lo, hi, elo, ehi, (leafMode == 0) ? ~leafBase : ~0, ~0);
+  writeNode(&outNodes[0], lo, hi, elo, ehi, leafRef, ~0);
   WideEntry e[4];
-  e[0].lo = lo; e[0].hi = hi; e[0].ref = (leafMode == 0) ? ~leafBase : ~0;
+  e[0].lo = lo; e[0].hi = hi; e[0].ref = leafRef;
   emptyEntry(e[1]); emptyEntry(e[2]); emptyEntry(e[3]);
   writeWideNode(outWide, e);
   nodeLo[0] = lo; nodeHi[0] = hi;
@@ -296,19 +341,35 @@ __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4
 //   [3..5.x] the three vertex tangents                                                  — GGX materials (TBN) only
 //   [5.y..7.y] the three vertex texture coordinates                                     — textured materials only
 __global__ void emitTrianglesKernel(const float* __restrict__ attributes, const unsigned int* __restrict__ indices,
+                                    const int4* __restrict__ soup, const DevInstance* __restrict__ instances,
                                     const unsigned long long* __restrict__ keys, int count, float4* __restrict__ triangles,
                                     float4* __restrict__ shadeTriangles)
 {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= count) return;
   const unsigned int prim = (unsigned int) (keys[slot] & 0xffffffffull);
-  const unsigned int i0 = indices[3 * prim], i1 = indices[3 * prim + 1], i2 = indices[3 * prim + 2];
-  const float* a = attributes + 12 * (size_t) i0;
-  const float* b = attributes + 12 * (size_t) i1;
-  const float* c = attributes + 12 * (size_t) i2;
-  triangles[3 * (size_t) slot + 0] = make_float4(a[0], a[1], a[2], __uint_as_float(prim));
-  triangles[3 * (size_t) slot + 1] = make_float4(b[0], b[1], b[2], 0.0f);
-  triangles[3 * (size_t) slot + 2] = make_float4(c[0], c[1], c[2], 0.0f);
+  const float *a, *b, *c;
+  if (soup != nullptr)
+  {
+    // world-space positions for traversal, tagged with primitive and instance; the shading record below stays in
+    // object space (shading transforms normals / tangents with the instance matrices as for any other hit)
+    const int4 d = soup[prim];
+    V3 wa, wb, wc;
+    soupVertices(d, attributes, indices, instances, a, b, c, wa, wb, wc);
+    triangles[3 * (size_t) slot + 0] = make_float4(wa.x, wa.y, wa.z, __int_as_float(d.w));
+    triangles[3 * (size_t) slot + 1] = make_float4(wb.x, wb.y, wb.z, __int_as_float(d.x));
+    triangles[3 * (size_t) slot + 2] = make_float4(wc.x, wc.y, wc.z, 0.0f);
+  }
+  else
+  {
+    const unsigned int i0 = indices[3 * prim], i1 = indices[3 * prim + 1], i2 = indices[3 * prim + 2];
+    a = attributes + 12 * (size_t) i0;
+    b = attributes + 12 * (size_t) i1;
+    c = attributes + 12 * (size_t) i2;
+    triangles[3 * (size_t) slot + 0] = make_float4(a[0], a[1], a[2], __uint_as_float(prim));
+    triangles[3 * (size_t) slot + 1] = make_float4(b[0], b[1], b[2], 0.0f);
+    triangles[3 * (size_t) slot + 2] = make_float4(c[0], c[1], c[2], 0.0f);
+  }
   const V3 v0 = v3(a[0], a[1], a[2]), v1 = v3(b[0], b[1], b[2]), v2 = v3(c[0], c[1], c[2]);
   const V3 ng = cross(v1 - v0, v2 - v0);
   float4* out = shadeTriangles + TWK_SHADE_RECORD * (size_t) slot;
@@ -342,6 +403,7 @@ hipError_t BvhBuilder::reserve(int count)
   BVH_CHECK(hipMalloc(&m_nodeLo, sizeof(float4) * n));
   BVH_CHECK(hipMalloc(&m_nodeHi, sizeof(float4) * n));
   BVH_CHECK(hipMalloc(&m_bounds, sizeof(unsigned int) * 8));
+  BVH_CHECK(hipMalloc(&m_leafPayload, sizeof(int) * n));
   m_sortBytes = 0;
   BVH_CHECK(rocprim::radix_sort_keys(nullptr, m_sortBytes, m_keysIn, m_keysOut, n, 0, 64, (hipStream_t) 0));
   BVH_CHECK(hipMalloc(&m_sortTemp, m_sortBytes > 0 ? m_sortBytes : 16));
@@ -351,22 +413,22 @@ hipError_t BvhBuilder::reserve(int count)
 
 void BvhBuilder::release()
 {
-  void* p[] = { m_primLo, m_primHi, m_keysIn, m_keysOut, m_left, m_right, m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, m_bounds, m_sortTemp };
+  void* p[] = { m_primLo, m_primHi, m_keysIn, m_keysOut, m_left, m_right, m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, m_bounds, m_sortTemp, m_leafPayload };
   for (void* q : p) if (q) (void) hipFree(q);
   m_primLo = m_primHi = m_nodeLo = m_nodeHi = nullptr;
   m_keysIn = m_keysOut = nullptr;
   m_left = m_right = m_innerParent = m_leafParent = nullptr; m_range = nullptr;
-  m_tickets = nullptr; m_bounds = nullptr; m_sortTemp = nullptr;
+  m_tickets = nullptr; m_bounds = nullptr; m_sortTemp = nullptr; m_leafPayload = nullptr;
   m_capacity = 0;
 }
 
-hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase)
+hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase, int leafFlag)
 {
   const int block = 256;
   const int grid  = (count + block - 1) / block;
   if (count == 1)
   {
-    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, outWide, m_nodeLo, m_nodeHi, leafMode, leafBase);
+    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, outWide, m_nodeLo, m_nodeHi, leafMode, leafBase, m_leafPayload, leafFlag);
     // keysOut[0] must still name primitive 0 for emitTriangles
     BVH_CHECK(hipMemsetAsync(m_keysOut, 0, sizeof(unsigned long long), stream));
     return hipGetLastError();
@@ -376,20 +438,21 @@ hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* ou
   BVH_CHECK(hipMemsetAsync(m_tickets, 0, sizeof(unsigned int) * count, stream));
   hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent, m_range);
   hipLaunchKernelGGL(refitKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_primLo, m_primHi, m_left, m_right,
-                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, outWide, nodeBase, leafMode, leafBase, m_maxLeaf);
+                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, outWide, nodeBase, leafMode, leafBase, m_maxLeaf, m_leafPayload, leafFlag);
   return hipGetLastError();
 }
 
 hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,
-                                      BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6])
+                                      BvhNode* outNodes, BvhNode* outWide, int nodeBase, float4* outTriangles, float4* outShadeTriangles, int triangleBase, float rootBounds[6],
+                                      const int4* soup, const DevInstance* instances)
 {
   BVH_CHECK(reserve(numTriangles));
   const int block = 256;
   const int grid  = (numTriangles + block - 1) / block;
   hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
-  hipLaunchKernelGGL(triangleBoxesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, numTriangles, m_primLo, m_primHi, m_bounds);
-  BVH_CHECK(buildFromBoxes(stream, numTriangles, outNodes, outWide, nodeBase, 0, triangleBase));
-  hipLaunchKernelGGL(emitTrianglesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, m_keysOut, numTriangles, outTriangles + 3 * (size_t) triangleBase, outShadeTriangles + TWK_SHADE_RECORD * (size_t) triangleBase);
+  hipLaunchKernelGGL(triangleBoxesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, soup, instances, numTriangles, m_primLo, m_primHi, m_bounds);
+  BVH_CHECK(buildFromBoxes(stream, numTriangles, outNodes, outWide, nodeBase, 0, triangleBase, soup ? TWK_LEAF_WORLD : 0));
+  hipLaunchKernelGGL(emitTrianglesKernel, dim3(grid), dim3(block), 0, stream, attributes, indices, soup, instances, m_keysOut, numTriangles, outTriangles + 3 * (size_t) triangleBase, outShadeTriangles + TWK_SHADE_RECORD * (size_t) triangleBase);
   BVH_CHECK(hipGetLastError());
   float4 lo, hi;
   BVH_CHECK(hipMemcpyAsync(&lo, m_nodeLo, sizeof(float4), hipMemcpyDeviceToHost, stream));
@@ -400,16 +463,22 @@ hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attribute
   return hipSuccess;
 }
 
-hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase)
+void BvhBuilder::soupDescriptors(hipStream_t stream, int4* soup, int first, int count, int instance, int attributeBase, int indexBase)
+{
+  hipLaunchKernelGGL(soupDescriptorsKernel, dim3((count + 255) / 256), dim3(256), 0, stream, soup, first, count, instance, attributeBase, indexBase);
+}
+
+hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, const int* hostLeafPayload, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase)
 {
   BVH_CHECK(reserve(numInstances));
   const int block = 256;
   const int grid  = (numInstances + block - 1) / block;
   BVH_CHECK(hipMemcpyAsync(m_primLo, hostLo, sizeof(float4) * numInstances, hipMemcpyHostToDevice, stream));
   BVH_CHECK(hipMemcpyAsync(m_primHi, hostHi, sizeof(float4) * numInstances, hipMemcpyHostToDevice, stream));
+  BVH_CHECK(hipMemcpyAsync(m_leafPayload, hostLeafPayload, sizeof(int) * numInstances, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
   hipLaunchKernelGGL(boxBoundsKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, numInstances, m_bounds);
-  BVH_CHECK(buildFromBoxes(stream, numInstances, outNodes, outWide, nodeBase, 1, 0));
+  BVH_CHECK(buildFromBoxes(stream, numInstances, outNodes, outWide, nodeBase, 1, 0, 0));
   BVH_CHECK(hipStreamSynchronize(stream)); // hostLo/hostHi may go away
   return hipSuccess;
 }

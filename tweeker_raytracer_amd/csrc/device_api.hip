@@ -6,6 +6,7 @@
 #include "bvh_build.h"
 #include "error_state.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,8 @@ void launchCompositor(const float4* tiles, float4* output, int width, int height
                       int tileSizeX, int tileShiftX, int tileShiftY, hipStream_t stream);
 void launchMathTap(int op, const float* x, const float* y, float* out, size_t n, hipStream_t stream);
 void launchStreamCopy(const float4* src, float4* dst, size_t n, hipStream_t stream);
+void launchGatherProbeFill(float4* table, size_t count, unsigned int lines, hipStream_t stream);
+void launchGatherProbe(const float4* table, unsigned int lines, int steps, float* out, int gridBlocks, hipStream_t stream);
 void launchTonemap(const float4* hdr, unsigned char* ldr, size_t numPixels, const TwkTonemapper& tm, hipStream_t stream);
 }
 
@@ -87,6 +90,9 @@ struct TwkDevice_t
   std::vector<GeometryHost>        geometries;
   std::vector<InstanceHost>        instances;
   bool built = false;
+  bool twoLevel = true;                 // some instance is entered through the top level (else the soup is the whole scene)
+  int  flattenMaxTriangles = TWK_FLATTEN_TRIANGLES, flattenMaxReferences = TWK_FLATTEN_REFERENCES;
+  int  maxInstanceMaterial = -1, maxInstanceLight = -1; // largest indices the built scene's instances use
 
   // device memory
   float* d_camera = nullptr;
@@ -204,6 +210,7 @@ static void refreshParams(TwkDevice dev)
   p.attributes = dev->d_attributes; p.indices = dev->d_indices;
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
+  p.twoLevel = dev->twoLevel ? 1 : 0;
   p.numInstances = (int) dev->instances.size();
   p.numLights = (int) dev->lights.size();
   p.miss = dev->miss;
@@ -239,8 +246,12 @@ static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * 6; } // 24 KiB 
 // (a 64-sample pass of a 1920x1080 frame takes 46 GB, a handle that renders two iterations takes 1.4 GB).
 static int ensureStreams(TwkDevice dev, int samples = 1)
 {
-  const int numPixels = dev->launchWidth * dev->state.resolution[1];
-  const int numPaths  = numPixels * (samples > 1 ? samples : 1);
+  const size_t wantPixels = (size_t) dev->launchWidth * (size_t) dev->state.resolution[1];
+  const size_t wantPaths  = wantPixels * (size_t) (samples > 1 ? samples : 1);
+  if (wantPaths >= ((size_t) 1 << 31)) // paths and queue slots are 32-bit indices; reported like a failed allocation so that the pass is cut in halves
+    return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "a pass of " + std::to_string(wantPaths) + " paths exceeds the 2^31 path indices of a wavefront pass");
+  const int numPixels = (int) wantPixels;
+  const int numPaths  = (int) wantPaths;
   if (numPixels > dev->allocatedPixels || dev->d_outputInternal == nullptr)
   {
     freeDevice(dev->d_outputInternal);
@@ -589,6 +600,8 @@ int twk_init_lights(TwkDevice dev, const TwkLightDefinition* l, int count)
 {
   int rc = activate(dev, "twk_init_lights"); if (rc) return rc;
   if (count < 0 || (count > 0 && !l)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_lights: bad arguments");
+  if (dev->built && count <= dev->maxInstanceLight)
+    return twkSetError(TWK_ERROR_INVALID_STATE, "twk_init_lights: the built scene has an instance with light index " + std::to_string(dev->maxInstanceLight) + "; " + std::to_string(count) + " lights would leave it dangling (twk_clear_scene first)");
   HIP_TRY(hipStreamSynchronize(dev->stream));
   freeDevice(dev->d_lights);
   dev->lights.assign(l, l + count);
@@ -614,6 +627,8 @@ int twk_init_materials(TwkDevice dev, const TwkMaterialGUI* m, int count)
 {
   int rc = activate(dev, "twk_init_materials"); if (rc) return rc;
   if (!m || count < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: at least one material is required");
+  if (dev->built && count <= dev->maxInstanceMaterial)
+    return twkSetError(TWK_ERROR_INVALID_STATE, "twk_init_materials: the built scene has an instance with material index " + std::to_string(dev->maxInstanceMaterial) + "; " + std::to_string(count) + " materials would leave it dangling (twk_clear_scene first)");
   for (int i = 0; i < count; ++i)
   {
     if (m[i].indexBSDF < 0 || m[i].indexBSDF > 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: indexBSDF out of range");
@@ -707,29 +722,70 @@ int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12], i
   return TWK_SUCCESS;
 }
 
+int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences)
+{
+  int rc = activate(dev, "twk_set_flatten_policy"); if (rc) return rc;
+  if (maxTriangles < 0 || maxReferences < 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_flatten_policy: limits must be >= 0");
+  dev->flattenMaxTriangles = maxTriangles; dev->flattenMaxReferences = maxReferences;
+  dev->built = false;
+  return TWK_SUCCESS;
+}
+
 int twk_build(TwkDevice dev)
 {
   int rc = activate(dev, "twk_build"); if (rc) return rc;
   if (dev->geometries.empty() || dev->instances.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: the scene has no geometry or no instance");
+  int maxMaterial = -1, maxLight = -1;
   for (const InstanceHost& inst : dev->instances)
   {
     if (inst.material >= (int) dev->materials.size()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: instance material index beyond twk_init_materials");
     if (inst.light >= (int) dev->lights.size()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: instance light index beyond twk_init_lights");
+    if (inst.material > maxMaterial) maxMaterial = inst.material;
+    if (inst.light > maxLight) maxLight = inst.light;
   }
   HIP_TRY(hipStreamSynchronize(dev->stream));
 
-  // shared attribute / index arrays and the node / triangle budgets
-  size_t numAttr = 0, numIdx = 0, numTris = 0, numNodes = 0;
-  for (GeometryHost& g : dev->geometries)
+  // Which instances are flattened (include/tweeker_hip.h twk_set_flatten_policy): those of tiny geometries and those
+  // whose geometry is referenced so rarely that instancing saves no memory worth the per-ray instance entry (ray
+  // transform, per-instance Woop constants, exit step). A flattened instance gets world-space triangle slots and an
+  // LBVH of its own whose root is spliced into the top level as an inner node: traversal walks from the top level
+  // straight into it with the untransformed ray.
+  const int numInstances = (int) dev->instances.size();
+  std::vector<int> references(dev->geometries.size(), 0);
+  for (const InstanceHost& inst : dev->instances) references[inst.geometry]++;
+  std::vector<char> flattened(numInstances, 0), needsBlas(dev->geometries.size(), 0);
+  int numEntered = 0, maxFlatTriangles = 0;
+  for (int i = 0; i < numInstances; ++i)
   {
+    const int g = dev->instances[i].geometry;
+    flattened[i] = (dev->geometries[g].numTriangles <= dev->flattenMaxTriangles) || (references[g] <= dev->flattenMaxReferences);
+    if (flattened[i]) maxFlatTriangles = std::max(maxFlatTriangles, dev->geometries[g].numTriangles);
+    else { needsBlas[g] = 1; ++numEntered; }
+  }
+
+  // shared attribute / index arrays and the node / triangle budgets: one bottom level per geometry that is still
+  // entered through an instance, one world-space tree per flattened instance, the top level
+  size_t numAttr = 0, numIdx = 0, numTris = 0, numNodes = 0;
+  for (size_t k = 0; k < dev->geometries.size(); ++k)
+  {
+    GeometryHost& g = dev->geometries[k];
     g.attributeBase = (unsigned int) numAttr; g.indexBase = (unsigned int) numIdx;
     g.triangleBase = (int) numTris; g.nodeBase = (int) numNodes;
     numAttr += g.attributes.size(); numIdx += g.indices.size();
-    numTris += (size_t) g.numTriangles; numNodes += (size_t) ((g.numTriangles > 1) ? g.numTriangles - 1 : 1);
+    if (needsBlas[k]) { numTris += (size_t) g.numTriangles; numNodes += (size_t) ((g.numTriangles > 1) ? g.numTriangles - 1 : 1); }
   }
-  const int numInstances = (int) dev->instances.size();
+  std::vector<int> flatTriangleBase(numInstances, -1), flatNodeBase(numInstances, -1);
+  for (int i = 0; i < numInstances; ++i)
+  {
+    if (!flattened[i]) continue;
+    const int n = dev->geometries[dev->instances[i].geometry].numTriangles;
+    flatTriangleBase[i] = (int) numTris; flatNodeBase[i] = (int) numNodes;
+    numTris += (size_t) n; numNodes += (size_t) ((n > 1) ? n - 1 : 1);
+  }
   const int tlasBase = (int) numNodes;
   numNodes += (size_t) ((numInstances > 1) ? numInstances - 1 : 1);
+  if (numTris >= ((size_t) 1 << 28) || numAttr >= ((size_t) 1 << 31) || numIdx >= ((size_t) 1 << 31))
+    return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_build: " + std::to_string(numTris) + " triangle slots; a leaf reference holds 28 bits of slot index");
 
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   HIP_TRY(hipMalloc(&dev->d_attributes, sizeof(TwkTriangleAttributes) * numAttr));
@@ -746,16 +802,17 @@ int twk_build(TwkDevice dev)
   }
 
   if (const char* e = getenv("TWK_MAX_LEAF")) dev->builder.setMaxLeaf(atoi(e)); // tuning knob, default 2 triangles per leaf
-  // bottom level: one LBVH per geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
-  for (GeometryHost& g : dev->geometries)
+  // bottom level: one LBVH per entered geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
+  for (size_t k = 0; k < dev->geometries.size(); ++k)
   {
+    GeometryHost& g = dev->geometries[k];
+    if (!needsBlas[k]) continue;
     HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes + 12 * (size_t) g.attributeBase, dev->d_indices + g.indexBase, g.numTriangles,
                                         dev->d_nodes + g.nodeBase, dev->d_wideNodes + 2 * (size_t) g.nodeBase, g.nodeBase, dev->d_triangles, dev->d_shadeTriangles, g.triangleBase, g.rootBounds));
   }
 
-  // instance records + world boxes
+  // instance records (shading reads them for every hit, flattened or not)
   std::vector<DevInstance> records(numInstances);
-  std::vector<float4> boxLo(numInstances), boxHi(numInstances);
   for (int i = 0; i < numInstances; ++i)
   {
     const InstanceHost& inst = dev->instances[i];
@@ -764,10 +821,34 @@ int twk_build(TwkDevice dev)
     memset(&r, 0, sizeof(r));
     memcpy(r.objectToWorld, inst.transform, sizeof(float) * 12);
     invertAffine(inst.transform, r.worldToObject);
-    r.blasRoot = g.nodeBase; r.material = inst.material; r.light = inst.light;
-    r.triangleFirst = g.triangleBase; r.triangleCount = g.numTriangles;
+    r.blasRoot = flattened[i] ? flatNodeBase[i] : g.nodeBase; r.material = inst.material; r.light = inst.light;
+    r.triangleFirst = flattened[i] ? flatTriangleBase[i] : g.triangleBase; r.triangleCount = g.numTriangles;
     r.attributeBase = g.attributeBase; r.indexBase = g.indexBase; r.geometry = inst.geometry;
+  }
+  HIP_TRY(hipMemcpyAsync(dev->d_instances, records.data(), sizeof(DevInstance) * numInstances, hipMemcpyHostToDevice, dev->stream));
 
+  // world-space trees of the flattened instances + the world boxes of all instances
+  std::vector<float4> boxLo(numInstances), boxHi(numInstances);
+  std::vector<int> leafPayload(numInstances);
+  ScopedDeviceBuffer<int4> soup;
+  if (maxFlatTriangles > 0) HIP_TRY(soup.allocate((size_t) maxFlatTriangles));
+  for (int i = 0; i < numInstances; ++i)
+  {
+    const InstanceHost& inst = dev->instances[i];
+    const GeometryHost& g = dev->geometries[inst.geometry];
+    if (flattened[i])
+    {
+      float bounds[6];
+      dev->builder.soupDescriptors(dev->stream, soup.ptr, 0, g.numTriangles, i, (int) g.attributeBase, (int) g.indexBase);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes, dev->d_indices, g.numTriangles,
+                                          dev->d_nodes + flatNodeBase[i], dev->d_wideNodes + 2 * (size_t) flatNodeBase[i], flatNodeBase[i],
+                                          dev->d_triangles, dev->d_shadeTriangles, flatTriangleBase[i], bounds, soup.ptr, dev->d_instances));
+      boxLo[i] = make_float4(bounds[0], bounds[1], bounds[2], 0.0f);
+      boxHi[i] = make_float4(bounds[3], bounds[4], bounds[5], 0.0f);
+      leafPayload[i] = ~flatNodeBase[i]; // child reference ~payload = the instance's root node: an inner reference
+      continue;
+    }
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int corner = 0; corner < 8; ++corner)
     {
@@ -784,12 +865,18 @@ int twk_build(TwkDevice dev)
     }
     boxLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
     boxHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    leafPayload[i] = i;
   }
-  HIP_TRY(hipMemcpyAsync(dev->d_instances, records.data(), sizeof(DevInstance) * numInstances, hipMemcpyHostToDevice, dev->stream));
-  HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), numInstances, dev->d_nodes + tlasBase, dev->d_wideNodes + 2 * (size_t) tlasBase, tlasBase));
+  if (numInstances == 1 && flattened[0]) dev->tlasRoot = flatNodeBase[0]; // the one world-space tree IS the scene
+  else
+  {
+    HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), leafPayload.data(), numInstances, dev->d_nodes + tlasBase, dev->d_wideNodes + 2 * (size_t) tlasBase, tlasBase));
+    dev->tlasRoot = tlasBase;
+  }
   HIP_TRY(hipStreamSynchronize(dev->stream));
 
-  dev->tlasRoot = tlasBase;
+  dev->twoLevel = (numEntered > 0);
+  dev->maxInstanceMaterial = maxMaterial; dev->maxInstanceLight = maxLight;
   dev->totalNodes = numNodes; dev->totalTriangles = numTris;
   dev->built = true;
   return TWK_SUCCESS;
@@ -993,6 +1080,31 @@ int twk_stream_peak_gbps(TwkDevice dev, size_t bytes, int repeats, float* gbps)
   (void) hipFree(a); (void) hipFree(b);
   if (e != hipSuccess) return twkSetError(TWK_ERROR_HIP, std::string("twk_stream_peak_gbps: ") + hipGetErrorString(e));
   *gbps = (float) (2.0 * (double) (n * sizeof(float4)) * repeats / ((double) ms * 1.0e-3) / 1.0e9);
+  return TWK_SUCCESS;
+}
+
+int twk_gather_peak(TwkDevice dev, size_t tableBytes, float* gigaLaneLoadsPerSecond)
+{
+  int rc = activate(dev, "twk_gather_peak"); if (rc) return rc;
+  if (!gigaLaneLoadsPerSecond || tableBytes < 128 * 1024 || tableBytes > ((size_t) 1 << 36)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_gather_peak: bad arguments");
+  const unsigned int lines = (unsigned int) (tableBytes / 128);
+  ScopedDeviceBuffer<float4> table; ScopedDeviceBuffer<float> out;
+  HIP_TRY(table.allocate((size_t) lines * 8));
+  HIP_TRY(out.allocate(1));
+  launchGatherProbeFill(table.ptr, (size_t) lines * 8, lines, dev->stream);
+  const int blocks = dev->numCUs * 6, steps = 1000; // 6 waves per SIMD, as the traversal kernel runs
+  launchGatherProbe(table.ptr, lines, 50, out.ptr, blocks, dev->stream); // warm-up: table into the caches
+  hipEvent_t e0, e1;
+  (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+  (void) hipEventRecord(e0, dev->stream);
+  launchGatherProbe(table.ptr, lines, steps, out.ptr, blocks, dev->stream);
+  (void) hipEventRecord(e1, dev->stream);
+  hipError_t e = hipStreamSynchronize(dev->stream);
+  float ms = 0.0f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+  if (e != hipSuccess) return twkSetError(TWK_ERROR_HIP, std::string("twk_gather_peak: ") + hipGetErrorString(e));
+  *gigaLaneLoadsPerSecond = (float) ((double) blocks * 256.0 * steps * 8.0 / ((double) ms * 1.0e-3) / 1.0e9);
   return TWK_SUCCESS;
 }
 

@@ -67,8 +67,8 @@ struct DevInstance
 {
   float worldToObject[12];
   int   blasRoot;      // node index of the geometry's BVH root in the shared node array
-  int   triangleFirst; // first triangle slot of the geometry
-  int   triangleCount; // <= TWK_INLINE_TRIANGLES: traversal tests the triangles right at the top-level leaf
+  int   triangleFirst; // first triangle slot of the geometry (flattened instance: of its own world-space slots)
+  int   triangleCount; // <= TWK_FLATTEN_TRIANGLES: the instance is flattened, traversal never enters it (see TWK_LEAF_WORLD)
   int   geometry;
   float objectToWorld[12];
   int   material;
@@ -77,9 +77,12 @@ struct DevInstance
   unsigned int indexBase;     // first index (uint) of the geometry in the shared index array
 };
 
-// Geometries with at most this many triangles (planes, the light quad, boxes' faces ...) have no bottom-level
-// descent: entering, one node, two leaves and leaving collapse into one step at the top-level leaf.
-#define TWK_INLINE_TRIANGLES 4
+// FLATTENED instances (include/tweeker_hip.h twk_set_flatten_policy: tiny geometries — planes, the light quad — and
+// geometries referenced so rarely that instancing saves nothing): the instance's triangles are written in WORLD space
+// into slots of its own (vertex .w of the second float4 = instance index) with an LBVH of its own, whose root is
+// spliced into the top level as an inner node. Its leaves carry TWK_LEAF_WORLD in the payload and are tested with
+// the world-space ray — no ray transform, no per-instance Woop constants, no descent, no exit step.
+#define TWK_LEAF_WORLD 0x40000000
 #define TWK_SHADE_RECORD 8 // float4 per shading record
 
 struct DevTexture
@@ -91,8 +94,8 @@ struct DevTexture
 };
 
 // BVH2 node, 64 B. Child reference: >= 0 inner node index; < 0 leaf, payload = ~ref:
-// bottom level: bits 0-27 first triangle slot in the reordered triangle array, bits 28-30 triangle count - 1;
-// top level: instance index.
+// bottom level: bits 0-27 first triangle slot in the reordered triangle array, bits 28-29 triangle count - 1;
+// top level: instance index; world-space tree of a flattened instance: TWK_LEAF_WORLD | the same slot-range packing.
 struct __attribute__((aligned(16))) BvhNode
 {
   float lo0[3]; float hi0x;
@@ -121,6 +124,7 @@ struct LaunchParams
   const float*       envCDF_U;
   const float*       envCDF_V;
   int   tlasRoot;
+  int   twoLevel;       // 0: every instance is flattened — the BVH is one world-space tree (top level + spliced instance trees) and no kernel ever enters an instance
   int   numInstances;
   int   numLights;
   int   miss;

@@ -302,6 +302,47 @@ __global__ void streamCopyKernel(const float4* __restrict__ src, float4* __restr
   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// Divergent-gather ceiling of the chip (measurement only, twk_gather_peak): every lane walks its own pseudo-random
+// chain of 128-byte lines through a table and reads the whole line as eight 16-byte loads — the access pattern of a
+// wide-node fetch. A CU takes one divergent lane address per clock, whatever the occupancy (MI355X: ~610 G
+// lane-loads/s from an L2-resident table), and THAT, not HBM, is the memory-side ceiling of traversal over a scene
+// that lives in the caches.
+__global__ void __launch_bounds__(256) gatherProbeKernel(const float4* __restrict__ table, unsigned int lines, int steps, float* out)
+{
+  unsigned int line = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u % lines;
+  float acc = 0.0f;
+  for (int s = 0; s < steps; ++s)
+  {
+    const float4* p = table + (size_t) line * 8;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k].x + v[k].y + v[k].z;
+    line = (__float_as_uint(v[0].w) + threadIdx.x) % lines; // dependent chain, like child references
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+__global__ void gatherProbeFillKernel(float4* table, size_t count, unsigned int lines)
+{
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < count; i += (size_t) gridDim.x * blockDim.x)
+  {
+    unsigned int x = (unsigned int) i * 1664525u + 1013904223u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    table[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(x % lines));
+  }
+}
+
+void launchGatherProbeFill(float4* table, size_t count, unsigned int lines, hipStream_t stream)
+{
+  hipLaunchKernelGGL(gatherProbeFillKernel, dim3(2048), dim3(256), 0, stream, table, count, lines);
+}
+void launchGatherProbe(const float4* table, unsigned int lines, int steps, float* out, int gridBlocks, hipStream_t stream)
+{
+  hipLaunchKernelGGL(gatherProbeKernel, dim3(gridBlocks), dim3(256), 0, stream, table, lines, steps, out);
+}
+
 void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);

@@ -147,7 +147,9 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
 
   TraceRay ray;
   setupRay(ray, org, dir);
-  WoopConstants woop;
+  WoopConstants woopWorld, woop; // world-space constants (flattened instances), current space
+  woopSetup(dir, woopWorld);
+  woop = woopWorld;
   V3 objOrg = org;
   int currentInstance = -1;
 
@@ -165,6 +167,7 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
     {
       // leaving an instance: back to the world-space ray
       setupRay(ray, org, dir);
+      woop = woopWorld; objOrg = org;
       currentInstance = -1;
       if (sp == 0) break;
       TWK_POP(node);
@@ -198,7 +201,7 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
 
     // leaf
     const int payload = ~node;
-    if (currentInstance < 0)
+    if (currentInstance < 0 && !(payload & TWK_LEAF_WORLD))
     {
       // top level: enter the instance
       const float4* rec = reinterpret_cast<const float4*>(p.instances + payload);
@@ -211,35 +214,6 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
       objOrg = transformPoint(m, org);
       const V3 objDir = transformVector(m, dir);
       woopSetup(objDir, woop);
-      const int triCountInst = __float_as_int(r3.z);
-      if (triCountInst <= TWK_INLINE_TRIANGLES)
-      {
-        // small geometry: test its triangles here, stay in the top level
-        const int first = __float_as_int(r3.y);
-        bool stop = false;
-        for (int slot = first; slot < first + triCountInst; ++slot)
-        {
-          const float4* tri = p.triangles + 3 * (size_t) slot;
-          const float4 a = tri[0], b = tri[1], c = tri[2];
-          if (COUNT) ++triCount;
-          float t, beta, gamma;
-          if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
-          {
-            const int prim = __float_as_int(a.w);
-            const bool closer = (t < res.t) ||
-                                (t == res.t && res.instance >= 0 &&
-                                 (payload < res.instance || (payload == res.instance && prim < res.primitive)));
-            if (closer)
-            {
-              res.t = t; res.beta = beta; res.gamma = gamma; res.instance = payload; res.primitive = prim; res.triangleSlot = slot;
-              if (anyHit) { stop = true; break; }
-            }
-          }
-        }
-        if (stop || sp == 0) break;
-        TWK_POP(node);
-        continue;
-      }
       setupRay(ray, objOrg, objDir);
       currentInstance = payload;
       TWK_PUSH(TWK_BVH_SENTINEL);
@@ -247,9 +221,10 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
       continue;
     }
 
-    // bottom level: a leaf of 1..8 consecutive triangle slots
+    // a leaf of 1..4 consecutive triangle slots: of the current instance's geometry (object space), or the world-space
+    // slots of a flattened instance at the top level (instance index in the slot)
     {
-      const int first = payload & 0x0fffffff, last = first + (payload >> 28);
+      const int first = payload & 0x0fffffff, last = first + ((payload >> 28) & 3);
       bool stop = false;
       for (int slot = first; slot <= last; ++slot)
       {
@@ -260,12 +235,13 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
         if (woopIntersect(woop, objOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma))
         {
           const int prim = __float_as_int(a.w);
+          const int triInstance = (currentInstance >= 0) ? currentInstance : __float_as_int(b.w);
           const bool closer = (t < res.t) ||
                               (t == res.t && res.instance >= 0 &&
-                               (currentInstance < res.instance || (currentInstance == res.instance && prim < res.primitive)));
+                               (triInstance < res.instance || (triInstance == res.instance && prim < res.primitive)));
           if (closer)
           {
-            res.t = t; res.beta = beta; res.gamma = gamma; res.instance = currentInstance; res.primitive = prim; res.triangleSlot = slot;
+            res.t = t; res.beta = beta; res.gamma = gamma; res.instance = triInstance; res.primitive = prim; res.triangleSlot = slot;
             if (anyHit) { stop = true; break; }
           }
         }

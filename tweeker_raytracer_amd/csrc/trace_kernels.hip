@@ -7,7 +7,9 @@
 // idle. Each lane walks the two-level BVH with its own stack — 4-ary wide nodes, TWK_TRACE_STACK_LDS entries in
 // LDS laid out [entry][lane] (bank = lane, conflict free); a ray whose stack would overflow is handed to
 // traceOverflowKernel, whose single-ray traverse() over the binary nodes continues the stack in HBM. Instances are
-// entered by transforming the ray into object space (t is preserved), exactly what an OptiX IAS→GAS descent does.
+// entered by transforming the ray into object space (t is preserved), exactly what an OptiX IAS→GAS descent does;
+// instances of tiny geometries (<= TWK_FLATTEN_TRIANGLES triangles: walls, light quads) were flattened into
+// world-space triangle slots at twk_build and are tested right at their top-level leaf with the world-space ray.
 //
 // Triangle test: watertight algorithm of Woop, Benthin, Wald (JCGT 2013), single precision with the
 // double fallback on zero edge functions, no fused multiply-add. Ties in t go to the smaller
@@ -72,7 +74,9 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 #define TWK_TRACE_NODE_FRACTION 4
 #endif
 
-template<bool COUNT, bool CUTOUT>
+// TWO_LEVEL = false: every instance of the scene is flattened (device_types.h TWK_LEAF_WORLD) — one world-space tree,
+// every leaf a triangle range; the instance entry / exit code is compiled out.
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL>
 #ifndef TWK_TRACE_WAVES
 #define TWK_TRACE_WAVES 6
 #endif
@@ -172,6 +176,7 @@ traceKernel(LaunchParams p, int depth)
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
             setupRay(ray, org, dir);
+            woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
             currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
           }
           poolBase += take; poolCount -= take;
@@ -246,12 +251,18 @@ traceKernel(LaunchParams p, int depth)
       {
         unsigned int pop = 0u; // lane flag kept in a vector register, like `state`
         TWK_WAVE_STEP(leafWaveSteps)
-        // Triangle range this lane tests in this round: the slots of a bottom-level leaf, or all triangles of a small
-        // geometry tested right at its top-level leaf. ONE copy of the triangle loop serves both kinds of lanes.
-        int triFirst = 0, triLast = -1, triInstance = currentInstance;
-        V3 triOrg = ray.o; // object-space origin (inside an instance ray.o is the transformed origin)
-        if (node == TWK_BVH_SENTINEL)
+        // Triangle range this lane tests in this round: the slots of a bottom-level leaf (object space, inside an
+        // instance) or the world-space slots of a flattened instance at the top level. ONE triangle loop serves both:
+        // `woop` and `ray.o` always belong to the space the lane is in.
+        int triFirst = 0, triLast = -1;
+        if (TWO_LEVEL && node == TWK_BVH_SENTINEL)
         {
+          // leaving an instance: the world-space Woop constants saved at entry come back from the stack
+          sp -= 4;
+          woop.perm = (unsigned int) ldsStack[sp * stride];
+          woop.Sx = __int_as_float(ldsStack[(sp + 1) * stride]);
+          woop.Sy = __int_as_float(ldsStack[(sp + 2) * stride]);
+          woop.Sz = __int_as_float(ldsStack[(sp + 3) * stride]);
           setupRay(ray, org, dir); // back to the world-space ray
           currentInstance = -1;
           pop = 1u;
@@ -259,41 +270,37 @@ traceKernel(LaunchParams p, int depth)
         else
         {
           const int payload = ~node;
-          if (currentInstance < 0)
+          if (TWO_LEVEL && currentInstance < 0 && !(payload & TWK_LEAF_WORLD))
           {
             const float4* rec = reinterpret_cast<const float4*>(p.instances + payload);
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             if (COUNT) ++instCount;
-            float m[12];
-            m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w;
-            m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
-            m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w;
-            const V3 objOrg = transformPoint(m, org);
-            const V3 objDir = transformVector(m, dir);
-            woopSetup(objDir, woop);
-            const int triCountInst = __float_as_int(r3.z);
-            if (triCountInst <= TWK_INLINE_TRIANGLES)
-            {
-              // small geometry: its triangles are tested here, the lane stays in the top level (no descent, no sentinel)
-              triFirst = __float_as_int(r3.y); triLast = triFirst + triCountInst - 1;
-              triInstance = payload; triOrg = objOrg;
-              pop = 1u;
-            }
+            if (sp + 5 > TWK_TRACE_STACK_LDS) state = (state & ~ST_HAS_RAY) | ST_DONE | ST_RETRACE;
             else
             {
+              // below the sentinel: the world-space Woop constants, restored when the sentinel is popped
+              ldsStack[sp * stride] = (int) woop.perm;
+              ldsStack[(sp + 1) * stride] = __float_as_int(woop.Sx);
+              ldsStack[(sp + 2) * stride] = __float_as_int(woop.Sy);
+              ldsStack[(sp + 3) * stride] = __float_as_int(woop.Sz);
+              ldsStack[(sp + 4) * stride] = TWK_BVH_SENTINEL;
+              sp += 5;
+              float m[12];
+              m[0] = r0.x; m[1] = r0.y; m[2] = r0.z; m[3] = r0.w;
+              m[4] = r1.x; m[5] = r1.y; m[6] = r1.z; m[7] = r1.w;
+              m[8] = r2.x; m[9] = r2.y; m[10] = r2.z; m[11] = r2.w;
+              const V3 objOrg = transformPoint(m, org);
+              const V3 objDir = transformVector(m, dir);
+              woopSetup(objDir, woop);
               setupRay(ray, objOrg, objDir);
               currentInstance = payload;
-              const bool full = (sp >= TWK_TRACE_STACK_LDS);
-              ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = TWK_BVH_SENTINEL;
-              ++sp;
               node = __float_as_int(r3.x);
-              if (full) state = (state & ~ST_HAS_RAY) | ST_DONE | ST_RETRACE;
             }
           }
           else
           {
-            // a leaf of 1..8 consecutive triangle slots (bvh_build.hip: at most TWK_MAX_LEAF, default 2)
-            triFirst = payload & 0x0fffffff; triLast = triFirst + (payload >> 28);
+            // a leaf of 1..4 consecutive triangle slots (bvh_build.hip: at most TWK_MAX_LEAF, default 2; a flattened instance: all of its triangles)
+            triFirst = payload & 0x0fffffff; triLast = triFirst + ((payload >> 28) & 3);
             pop = 1u;
           }
         }
@@ -305,8 +312,9 @@ traceKernel(LaunchParams p, int depth)
           if (COUNT) ++triCount;
           TWK_WAVE_STEP(triWaveSteps)
           float t, beta, gamma;
-          const bool hit = woopIntersect(woop, triOrg, v3(a), v3(b), v3(c), tmin, t, beta, gamma);
+          const bool hit = woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma);
           const int prim = __float_as_int(a.w);
+          const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b.w); // world-space slots carry their instance
           const bool closer = hit & ((t < res.t) |
                                      ((t == res.t) & (res.instance >= 0) &
                                       ((triInstance < res.instance) | ((triInstance == res.instance) & (prim < res.primitive)))));
@@ -345,6 +353,7 @@ traceKernel(LaunchParams p, int depth)
           res.t = isShadow ? p.shadowDir[slot - numClosest].w : p.rayDir[q][slot].w;
           res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
           setupRay(ray, org, dir);
+          woopSetup(dir, woop);
           currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
           state |= ST_HAS_RAY;
         }
@@ -485,15 +494,28 @@ traceQueryKernel(LaunchParams p, const float* __restrict__ rays, unsigned int nu
   }
 }
 
-void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream)
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL>
+static void launchTraceVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
-  const dim3 grid(gridBlocks), ogrid(overflowBlocks), block(TWK_TRACE_BLOCK);
-  const bool cutout = (p.hasCutout != 0);
-  if (count && cutout)       { hipLaunchKernelGGL((traceKernel<true, true>),   grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<true, true>),   ogrid, block, 0, stream, p, depth); }
-  else if (count)            { hipLaunchKernelGGL((traceKernel<true, false>),  grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<true, false>),  ogrid, block, 0, stream, p, depth); }
-  else if (cutout)           { hipLaunchKernelGGL((traceKernel<false, true>),  grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<false, true>),  ogrid, block, 0, stream, p, depth); }
-  else                       { hipLaunchKernelGGL((traceKernel<false, false>), grid, block, 0, stream, p, depth); hipLaunchKernelGGL((traceOverflowKernel<false, false>), ogrid, block, 0, stream, p, depth); }
+  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+}
+
+void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream)
+{
+  const int variant = (count ? 4 : 0) | (p.hasCutout ? 2 : 0) | (p.twoLevel ? 1 : 0);
+  switch (variant)
+  {
+    case 0: launchTraceVariant<false, false, false>(p, depth, gridBlocks, stream); break;
+    case 1: launchTraceVariant<false, false, true >(p, depth, gridBlocks, stream); break;
+    case 2: launchTraceVariant<false, true,  false>(p, depth, gridBlocks, stream); break;
+    case 3: launchTraceVariant<false, true,  true >(p, depth, gridBlocks, stream); break;
+    case 4: launchTraceVariant<true,  false, false>(p, depth, gridBlocks, stream); break;
+    case 5: launchTraceVariant<true,  false, true >(p, depth, gridBlocks, stream); break;
+    case 6: launchTraceVariant<true,  true,  false>(p, depth, gridBlocks, stream); break;
+    default: launchTraceVariant<true, true,  true >(p, depth, gridBlocks, stream); break;
+  }
 }
 
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream)

@@ -105,6 +105,11 @@ class Device:
         L.check(L.lib.twk_add_instance(self._h, int(idGeometry), t, int(idMaterial), int(idLight), C.byref(iid)))
         return iid.value
 
+    def setFlattenPolicy(self, maxTriangles, maxReferences):
+        """Build option of the next build(): instances of geometries with <= maxTriangles triangles, or referenced by
+        <= maxReferences instances, are intersected in world space in one single-level BVH; (0, 0) = pure two-level."""
+        L.check(L.lib.twk_set_flatten_policy(self._h, int(maxTriangles), int(maxReferences)))
+
     def build(self):
         L.check(L.lib.twk_build(self._h))
 
@@ -187,6 +192,12 @@ class Device:
     def streamPeakGBps(self, nbytes=1 << 30, repeats=10):
         g = C.c_float(0)
         L.check(L.lib.twk_stream_peak_gbps(self._h, C.c_size_t(nbytes), int(repeats), C.byref(g)))
+        return g.value
+
+    def gatherPeak(self, table_bytes=32 << 20):
+        """Divergent-gather ceiling in giga lane-loads (16 B each) per second (twk_gather_peak)."""
+        g = C.c_float(0)
+        L.check(L.lib.twk_gather_peak(self._h, C.c_size_t(int(table_bytes)), C.byref(g)))
         return g.value
 
     def debugCapture(self, enable=True):
