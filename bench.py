@@ -244,7 +244,8 @@ def main():
         gather_peak = dev.gatherPeak(32 << 20)              # G lane-loads/s (16 B each) from a scene-sized, cache-resident table
         rays = st["radianceRays"] + st["shadowRays"]
         algo_bytes = B_RAY_FIXED * rays + B_NODE * st["nodesVisited"] + B_TRIANGLE * st["trianglesTested"] + B_INSTANCE * st["instancesEntered"]
-        lane_loads = L_RAY * rays + L_NODE * st["nodesVisited"] + L_TRIANGLE * st["trianglesTested"] + L_INSTANCE * st["instancesEntered"]
+        memory_nodes = st["nodesVisited"] - st["cachedNodesVisited"]  # the top of the tree is served from LDS (TWK_NODE_CACHED)
+        lane_loads = L_RAY * rays + L_NODE * memory_nodes + L_TRIANGLE * st["trianglesTested"] + L_INSTANCE * st["instancesEntered"]
         trace_ms, trace_launches = prof["trace"]["ms"], max(1, prof["trace"]["launches"])
         trace_s = max(trace_ms * 1.0e-3, 1e-12)
         algo_gbps = algo_bytes / trace_s / 1.0e9
@@ -283,7 +284,7 @@ def main():
             "frac": gather_gbps / (gather_peak * 16.0),
             "traffic": traffic,
             "traffic_note": traffic_note,
-            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued (2 per ray, 8 per wide node, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel beyond memory (vector issue at partial lane occupancy): DESIGN.md 4.1",
+            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued to the vector memory path (2 per ray, 8 per wide node NOT served by the LDS top-of-tree cache, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel beyond memory (vector issue at partial lane occupancy): DESIGN.md 4.1",
             "fractions": fractions,
             "stream_peak_gbps_measured": stream_peak,
             "hbm_spec_gbps": HBM_SPEC_GBPS,
@@ -295,6 +296,7 @@ def main():
             "launches": trace_launches,
             "rays_per_step": rays / args.steps,
             "nodes_per_ray": st["nodesVisited"] / max(1, rays),
+            "nodes_per_ray_from_lds_cache": st["cachedNodesVisited"] / max(1, rays),
             "triangles_per_ray": st["trianglesTested"] / max(1, rays),
             "instance_entries_per_ray": st["instancesEntered"] / max(1, rays),
             "lane_occupancy": {"node_step": st["nodesVisited"] / max(1, 64 * st["nodeWaveSteps"]),

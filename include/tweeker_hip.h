@@ -138,7 +138,7 @@ typedef struct TwkLaunchStats
 {
   uint64_t radianceRays;    /* closest-hit rays traced */
   uint64_t shadowRays;      /* any-hit rays traced */
-  uint64_t nodesVisited;    /* BVH2 nodes fetched (64 B each), both ray kinds */
+  uint64_t nodesVisited;    /* 4-ary wide nodes visited (128 B each), both ray kinds */
   uint64_t trianglesTested; /* triangle records fetched (48 B each) */
   uint64_t instancesEntered;
   uint64_t shadedHits;
@@ -152,6 +152,7 @@ typedef struct TwkLaunchStats
   uint64_t nodeWaveSteps;     /* wave-level iterations of the node step: lane occupancy there = nodesVisited / (64 * nodeWaveSteps) */
   uint64_t triangleWaveSteps; /* wave-level iterations of the triangle test */
   uint64_t leafWaveSteps;     /* wave-level executions of the leaf / instance entry / instance exit step */
+  uint64_t cachedNodesVisited; /* of nodesVisited: wide nodes served from the LDS top-of-tree cache, not from memory */
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */

@@ -2,12 +2,16 @@
 # A/B helper: build a variant of the library that differs only in the compile-time knobs of trace_kernels.hip
 # (e.g. -DTWK_TRACE_WAVES=7 -DTWK_TRACE_STACK_LDS=20) into build/lib_<name>.so; the other objects are reused.
 # usage: tools/ab_variant.sh <name> <extra hipcc flags...>     then on the GPU box:
-#        cp build/lib_<name>.so tweeker_raytracer_amd/libtweeker_hip.so && python bench.py --no-cpu-baseline
+#        TWK_LIB=build/lib_<name>.so python bench.py --no-cpu-baseline
+# (flags that change device_types.h constants used by other objects, e.g. TWK_TRACE_STACK_LDS, rebuild those too)
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../tweeker_raytracer_amd/csrc"
 make -s > /dev/null
-mkdir -p ../../build
-hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function "$@" -c trace_kernels.hip -o ../../build/trace_$NAME.o 2>&1 | grep -E "error" || true
-hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/lib_$NAME.so device_api.o bvh_build.o ../../build/trace_$NAME.o shade_kernels.o tail_kernel.o host/description_parser.o host/triangle_meshes.o host/application.o host/image_files.o host/host_cabi.o -lz
+mkdir -p ../../build/$NAME
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function"
+for f in trace_kernels tail_kernel bvh_build device_api shade_kernels; do
+  hipcc $FLAGS "$@" -c $f.hip -o ../../build/$NAME/$f.o 2>&1 | grep -E "error" || true
+done
+hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/lib_$NAME.so ../../build/$NAME/device_api.o ../../build/$NAME/bvh_build.o ../../build/$NAME/trace_kernels.o ../../build/$NAME/shade_kernels.o ../../build/$NAME/tail_kernel.o host/description_parser.o host/triangle_meshes.o host/application.o host/image_files.o host/host_cabi.o -lz
 ls -la ../../build/lib_$NAME.so

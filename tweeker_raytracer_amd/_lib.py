@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtweeker_hip.so")
+LIB_PATH = os.environ.get("TWK_LIB") or os.path.join(_HERE, "libtweeker_hip.so")  # TWK_LIB: an A/B variant built by tools/ab_variant.sh
 
 
 class TwkError(RuntimeError):
@@ -69,7 +69,8 @@ class LaunchStats(C.Structure):
                 ("missed", C.c_uint64), ("maxNodesPerRay", C.c_uint64), ("tailRays", C.c_uint64),
                 ("tailNodesVisited", C.c_uint64), ("tailTrianglesTested", C.c_uint64), ("tailInstancesEntered", C.c_uint64),
                 ("overflowRays", C.c_uint64),
-                ("nodeWaveSteps", C.c_uint64), ("triangleWaveSteps", C.c_uint64), ("leafWaveSteps", C.c_uint64)]
+                ("nodeWaveSteps", C.c_uint64), ("triangleWaveSteps", C.c_uint64), ("leafWaveSteps", C.c_uint64),
+                ("cachedNodesVisited", C.c_uint64)]
 
 
 class AppInfo(C.Structure):

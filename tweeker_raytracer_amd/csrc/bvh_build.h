@@ -3,6 +3,10 @@
 
 namespace twk {
 
+// Copies the first TWK_TOP_NODES wide nodes (breadth-first from `root`) into top[TWK_TOP_NODES * 8] with the references
+// among them rewritten to TWK_NODE_CACHED | slot (device_types.h).
+void launchTopCache(const BvhNode* wide, int root, float4* top, hipStream_t stream);
+
 // Scratch-owning LBVH builder, reused for every geometry (bottom level) and for the instance level.
 class BvhBuilder
 {

@@ -383,6 +383,47 @@ __global__ void emitTrianglesKernel(const float* __restrict__ attributes, const 
   out[7] = make_float4(c[10], c[11], 0.0f, 0.0f);
 }
 
+// Top-of-tree cache (device_types.h TWK_NODE_CACHED): breadth-first from the root over the wide nodes, the first
+// TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One thread: 16 nodes.
+__global__ void topCacheKernel(const BvhNode* __restrict__ wide, int root, float4* __restrict__ top)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int queue[TWK_TOP_NODES];
+  int n = 1;
+  queue[0] = root;
+  for (int i = 0; i < n; ++i)
+  {
+    const float4* w = reinterpret_cast<const float4*>(wide + 2 * (size_t) queue[i]);
+    for (int k = 0; k < 4; ++k)
+    {
+      const int ref = __float_as_int(w[k].w);
+      if (ref >= 0 && ref != TWK_BVH_SENTINEL && n < TWK_TOP_NODES) queue[n++] = ref;
+    }
+  }
+  for (int i = 0; i < TWK_TOP_NODES; ++i)
+  {
+    float4* out = top + 8 * i;
+    if (i >= n) { for (int k = 0; k < 8; ++k) out[k] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(~0)); continue; }
+    const float4* w = reinterpret_cast<const float4*>(wide + 2 * (size_t) queue[i]);
+    for (int k = 0; k < 8; ++k)
+    {
+      float4 v = w[k];
+      if (k < 4)
+      {
+        const int ref = __float_as_int(v.w);
+        if (ref >= 0)
+          for (int j = 0; j < n; ++j) if (queue[j] == ref) { v.w = __int_as_float(TWK_NODE_CACHED | j); break; }
+      }
+      out[k] = v;
+    }
+  }
+}
+
+void launchTopCache(const BvhNode* wide, int root, float4* top, hipStream_t stream)
+{
+  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wide, root, top);
+}
+
 #define BVH_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t BvhBuilder::reserve(int count)

@@ -100,6 +100,7 @@ struct TwkDevice_t
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
+  float4* d_topNodes = nullptr; bool topCache = true; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
   int tlasRoot = 0;
@@ -210,6 +211,8 @@ static void refreshParams(TwkDevice dev)
   p.attributes = dev->d_attributes; p.indices = dev->d_indices;
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
+  p.topNodes = dev->d_topNodes;
+  p.topRoot = dev->topCache ? (TWK_NODE_CACHED | 0) : dev->tlasRoot;
   p.twoLevel = dev->twoLevel ? 1 : 0;
   p.numInstances = (int) dev->instances.size();
   p.numLights = (int) dev->lights.size();
@@ -276,7 +279,7 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     dev->allocatedPaths = numPaths;
   }
   if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
-  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 16)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 16, dev->stream)); }
+  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 24)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 24, dev->stream)); }
   const size_t lanes = (size_t) traceGridBlocks(dev) * TWK_TRACE_BLOCK;
   if (lanes > dev->spillLanes)
   {
@@ -521,6 +524,7 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
   }
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
+  if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
   if (const char* e = getenv("TWK_STREAM_BUDGET_MB")) { const long long mb = atoll(e); dev->streamBudgetBytes = (mb > 0) ? (size_t) mb << 20 : 0; }
   if (const char* e = getenv("TWK_BATCH")) { const int b = atoi(e); dev->batchMax = (b < 1) ? 1 : ((b > 64) ? 64 : b); }
   *out = dev;
@@ -538,7 +542,7 @@ int twk_device_destroy(TwkDevice dev)
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
   freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
-  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V);
+  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
   freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
   freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
@@ -873,6 +877,9 @@ int twk_build(TwkDevice dev)
     HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), leafPayload.data(), numInstances, dev->d_nodes + tlasBase, dev->d_wideNodes + 2 * (size_t) tlasBase, tlasBase));
     dev->tlasRoot = tlasBase;
   }
+  if (!dev->d_topNodes) HIP_TRY(hipMalloc(&dev->d_topNodes, sizeof(float4) * 8 * TWK_TOP_NODES));
+  launchTopCache(dev->d_wideNodes, dev->tlasRoot, dev->d_topNodes, dev->stream);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
 
   dev->twoLevel = (numEntered > 0);
@@ -1048,12 +1055,13 @@ int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
   memset(stats, 0, sizeof(*stats));
   if (!dev->d_stats) return TWK_SUCCESS;
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  unsigned long long h[16];
+  unsigned long long h[24];
   HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
   stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
   stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
+  stats->cachedNodesVisited = h[16];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }

@@ -70,8 +70,12 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 #ifndef TWK_TRACE_REFILL
 #define TWK_TRACE_REFILL 44
 #endif
-#ifndef TWK_TRACE_NODE_FRACTION
-#define TWK_TRACE_NODE_FRACTION 4
+// The node loop of a round ends once fewer than NUM/DEN of the lanes that entered it are still at an inner node.
+#ifndef TWK_TRACE_NODE_NUM
+#define TWK_TRACE_NODE_NUM 1
+#endif
+#ifndef TWK_TRACE_NODE_DEN
+#define TWK_TRACE_NODE_DEN 2
 #endif
 
 // TWO_LEVEL = false: every instance of the scene is flattened (device_types.h TWK_LEAF_WORLD) — one world-space tree,
@@ -84,8 +88,11 @@ __global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // waves/SIM
 traceKernel(LaunchParams p, int depth)
 {
   __shared__ int stackStorage[(TWK_TRACE_STACK_LDS + 1) * TWK_TRACE_BLOCK]; // + 1 dummy row, see the node step
+  __shared__ float4 topCache[TWK_TOP_NODES * TWK_TOP_STRIDE];               // device_types.h TWK_NODE_CACHED
   int* ldsStack = stackStorage + threadIdx.x;
   const int stride = TWK_TRACE_BLOCK;
+  if (threadIdx.x < TWK_TOP_NODES * 8) topCache[(threadIdx.x >> 3) * TWK_TOP_STRIDE + (threadIdx.x & 7)] = p.topNodes[threadIdx.x];
+  __syncthreads();
 
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const unsigned int numShadow  = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + 1] : 0u;
@@ -96,7 +103,7 @@ traceKernel(LaunchParams p, int depth)
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
-  unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0, maxSteps = 0;
+  unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0, maxSteps = 0, cachedCount = 0;
   unsigned int nodeWaveSteps = 0, triWaveSteps = 0, leafWaveSteps = 0; // COUNT: wave-level iterations, tallied by the first active lane (lane occupancy = lane count / (64 * wave steps))
 #define TWK_WAVE_STEP(counter) if (COUNT) { if (lane == (unsigned int) (__ffsll((long long) __ballot(true)) - 1)) ++(counter); }
 
@@ -177,7 +184,7 @@ traceKernel(LaunchParams p, int depth)
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
             setupRay(ray, org, dir);
             woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
-            currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
+            currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
           }
           poolBase += take; poolCount -= take;
         }
@@ -200,8 +207,18 @@ traceKernel(LaunchParams p, int depth)
       while ((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
         // one WIDE node = the four grandchildren of binary node `node`: two levels per round of loads
-        const float4* w = reinterpret_cast<const float4*>(p.wideNodes + 2 * (size_t) node);
-        const float4 l0 = w[0], u0 = w[1], l1 = w[2], u1 = w[3], l2 = w[4], u2 = w[5], l3 = w[6], u3 = w[7];
+        float4 l0, u0, l1, u1, l2, u2, l3, u3;
+        if (node & TWK_NODE_CACHED)
+        {
+          const float4* w = topCache + (node & 0xff) * TWK_TOP_STRIDE; // the top of the tree, from LDS
+          if (COUNT) ++cachedCount;
+          l0 = w[0]; u0 = w[1]; l1 = w[2]; u1 = w[3]; l2 = w[4]; u2 = w[5]; l3 = w[6]; u3 = w[7];
+        }
+        else
+        {
+          const float4* w = reinterpret_cast<const float4*>(p.wideNodes + 2 * (size_t) node);
+          l0 = w[0]; u0 = w[1]; l1 = w[2]; u1 = w[3]; l2 = w[4]; u2 = w[5]; l3 = w[6]; u3 = w[7];
+        }
         ++guard;
         if (COUNT) ++nodeCount;
         TWK_WAVE_STEP(nodeWaveSteps)
@@ -242,7 +259,7 @@ traceKernel(LaunchParams p, int depth)
         if (stop | overflow) state = (state & ~ST_HAS_RAY) | ST_DONE;
         // Leave the node loop once most lanes are parked at a leaf: the stragglers resume in the next round
         // together with the lanes that come back from their leaf, instead of running at a few lanes per wave.
-        if (__popcll(__ballot((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_FRACTION < roundActive) break;
+        if (__popcll(__ballot((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_DEN < roundActive * TWK_TRACE_NODE_NUM) break;
       }
 
       // one leaf / instance-entry / instance-exit step per lane; lanes that left the node loop early are still
@@ -354,7 +371,7 @@ traceKernel(LaunchParams p, int depth)
           res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
           setupRay(ray, org, dir);
           woopSetup(dir, woop);
-          currentInstance = -1; sp = 0; node = p.tlasRoot; guard = 0;
+          currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
           state |= ST_HAS_RAY;
         }
         else if (state & ST_OVERFLOWED) { state &= ~ST_OVERFLOWED; }
@@ -403,6 +420,7 @@ traceKernel(LaunchParams p, int depth)
     if (nodeWaveSteps) atomicAdd(&p.stats[13], (unsigned long long) nodeWaveSteps);
     if (triWaveSteps)  atomicAdd(&p.stats[14], (unsigned long long) triWaveSteps);
     if (leafWaveSteps) atomicAdd(&p.stats[15], (unsigned long long) leafWaveSteps);
+    if (cachedCount)   atomicAdd(&p.stats[16], (unsigned long long) cachedCount);
   }
 #undef TWK_WAVE_STEP
 }
