@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TWK_ABI_VERSION 1
+#define TWK_ABI_VERSION 2
 
 typedef enum TwkResult
 {
@@ -214,12 +214,27 @@ int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences);
 int twk_launch(TwkDevice dev, unsigned int iterationIndex);
 int twk_sync(TwkDevice dev);                                  /* ≙ Device::synchronizeStream */
 /* twk_launch is asynchronous and deferred: consecutive iteration indices are rendered together, up to `iterations`
- * samples per pixel per wavefront pass (1..64, default 64; 344 bytes of path streams per sample and pixel), as soon
+ * samples per pixel per wavefront pass (1..64, default 64; 280 bytes of path streams per sample and pixel), as soon
  * as the batch is full or any other call observes the device. The image is bit-identical to one pass per iteration; 1 restores strict one-launch-per-call behaviour. */
 int twk_set_launch_batch(TwkDevice dev, int iterations);
 /* The path streams of a pass are allocated on demand and grow with the largest pass seen; this allocates them up
  * front for passes of `iterations` samples per pixel, so that no allocation falls into a timed or interactive loop. */
 int twk_reserve_launch_batch(TwkDevice dev, int iterations);
+
+/* The two apps the hot path serves differ in ONE rule of __closesthit__radiance: rtigo3 ends a path on a light only
+ * when its lit side is hit and lets a back-face hit fall through to the light's BSDF (apps/rtigo3/shaders/closesthit.cu:192-222);
+ * Optix7Gui (intro_07's app) ends the path on either side, black on the back face (apps/Optix7Gui/shaders/closesthit.cu:189-226). */
+enum { TWK_SHADERS_RTIGO3 = 0, TWK_SHADERS_OPTIX7GUI = 1 };
+int twk_set_shader_variant(TwkDevice dev, int variant);
+
+/* Denoiser AOVs of Optix7Gui's integrator (apps/Optix7Gui/shaders/raygeneration.cu:125-164,239-262), the input the
+ * OptiX AI denoiser is fed with (the denoiser itself is closed third-party code and not part of this library):
+ * TWK_AOV_ALBEDO: throughput-attenuated albedo of the first diffuse or light event, clamped to [0, 1], alpha 1;
+ * TWK_AOV_NORMAL: shading normal of the primary hit in right-handed camera space, renormalised running mean, w 0.
+ * Both accumulate like the radiance (running mean, skipped with it when a sample is NaN). Layout as twk_read_output. */
+enum { TWK_AOV_ALBEDO = 0, TWK_AOV_NORMAL = 1 };
+int twk_enable_aov(TwkDevice dev, int enable);
+int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats);
 
 /* Output. With distribution 0 the buffer is W×H (≙ outputBuffer); with distribution 1 it is the
  * packed launchWidth×H local tile buffer (≙ texelBuffer, DeviceMultiGPULocalCopy.cpp:109-172). */
@@ -298,6 +313,7 @@ typedef struct TwkAppInfo
   float epsilonFactor, envRotation, clockFactor;
   float center[3], phi, theta, fov, distance;
   int   numCameras, numLights, numMaterials, numGeometries, numInstances;
+  int   shaderVariant; /* "shaderVariant" of the system description (grammar extension): TWK_SHADERS_*; applied by twk_app_init_device */
 } TwkAppInfo;
 
 int twk_app_info(TwkApp app, TwkAppInfo* info);

@@ -109,6 +109,7 @@ class Oracle:
     def loadApplication(self, app, distribution=None, state=None):
         """Feed the scene an Application parsed (same inputs twk_app_init_device hands to the HIP device)."""
         st = state if state is not None else app.state
+        self.setShaderVariant(getattr(app.info, "shaderVariant", 0))
         if distribution is not None:
             st.distribution = int(distribution)
         self.setState(st)
@@ -125,6 +126,18 @@ class Oracle:
     def setFlattenPolicy(self, maxTriangles, maxReferences):
         """≙ Device.setFlattenPolicy: which instances are intersected in world space (include/tweeker_hip.h)."""
         self._chk(self.lib.orc_set_flatten_policy(self._h, int(maxTriangles), int(maxReferences)))
+
+    def setShaderVariant(self, variant):
+        self._chk(self.lib.orc_set_shader_variant(self._h, int(variant)))
+
+    def enableAov(self, enable=True):
+        self._chk(self.lib.orc_enable_aov(self._h, int(bool(enable))))
+
+    def readAov(self, which):
+        h, w = self.state.resolution[1], self.launchWidth
+        out = np.empty((h, w, 4), dtype=np.float32)
+        self._chk(self.lib.orc_read_aov(self._h, int(which), _f(out), C.c_size_t(out.size)))
+        return out
 
     def setTraceMode(self, use_bvh):
         self._chk(self.lib.orc_set_trace_mode(self._h, int(bool(use_bvh))))

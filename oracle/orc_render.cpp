@@ -25,6 +25,9 @@ struct Oracle
   std::vector<Hit>    firstHits;  // per launch index, filled by the last render when captureFirstHits
   bool captureFirstHits = false;
   int  launchWidth = 1;
+  int  shaderVariant = TWK_SHADERS_RTIGO3; // which app's __closesthit__radiance rule for light hits (include/tweeker_hip.h)
+  bool aov = false;                        // Optix7Gui's denoiser AOVs (raygeneration.cu:125-164,239-262)
+  std::vector<float4> aovAlbedo, aovNormal;
   uint64_t radianceRays = 0, shadowRays = 0, samples = 0;
 };
 
@@ -155,14 +158,16 @@ static void missProgram(const Oracle& o, PerRayData* thePrd)
   {
     case 0:
       thePrd->radiance = make_float3(0.0f);
-      thePrd->flags |= FLAG_TERMINATE;
+      thePrd->albedo   = make_float3(0.0f); // Optix7Gui miss.cu:47-50 (FLAG_LIGHT too)
+      thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
       break;
     default:
     case 1:
     {
       const float weightMIS = (thePrd->flags & FLAG_DIFFUSE) ? powerHeuristic(thePrd->pdf, 0.25f * M_1_PIf_) : 1.0f;
       thePrd->radiance = make_float3(weightMIS);
-      thePrd->flags |= FLAG_TERMINATE;
+      thePrd->albedo   = make_float3(1.0f); // Optix7Gui miss.cu:67-71
+      thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
       break;
     }
     case 2:
@@ -179,7 +184,8 @@ static void missProgram(const Oracle& o, PerRayData* thePrd)
         weightMIS = powerHeuristic(thePrd->pdf, pdfLight);
       }
       thePrd->radiance = emission * weightMIS;
-      thePrd->flags |= FLAG_TERMINATE;
+      thePrd->albedo   = emission;          // Optix7Gui miss.cu:105-109
+      thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
       break;
     }
   }
@@ -225,9 +231,31 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
     state.normal    = -state.normal;
   }
 
+  thePrd->normal = state.normal; // Optix7Gui closesthit.cu:183-185
   thePrd->radiance = make_float3(0.0f);
 
-  if (0 <= hc.inst->light && (thePrd->flags & FLAG_FRONTFACE))
+  if (0 <= hc.inst->light && o.shaderVariant == TWK_SHADERS_OPTIX7GUI)
+  {
+    // apps/Optix7Gui/shaders/closesthit.cu:189-226: a light ends the path whichever side is hit, black on the back face
+    float3 emission = make_float3(0.0f);
+    const float cosTheta = dot(thePrd->wo, state.normalGeo);
+    if ((thePrd->flags & FLAG_FRONTFACE) && DENOMINATOR_EPSILON < cosTheta)
+    {
+      LightDefinition const& light = sysData.lightDefinitions[hc.inst->light];
+      emission = light.emission;
+      const float lightPdf = (thePrd->distance * thePrd->distance) / (light.area * cosTheta);
+      if ((thePrd->flags & FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
+      {
+        emission *= powerHeuristic(thePrd->pdf, lightPdf);
+      }
+    }
+    thePrd->radiance = emission;
+    thePrd->albedo   = emission;
+    thePrd->flags |= (FLAG_HIT | FLAG_LIGHT | FLAG_TERMINATE);
+    return;
+  }
+
+  if (0 <= hc.inst->light && (thePrd->flags & FLAG_FRONTFACE)) // apps/rtigo3/shaders/closesthit.cu:192-222
   {
     const float cosTheta = dot(thePrd->wo, state.normalGeo);
     if (DENOMINATOR_EPSILON < cosTheta)
@@ -240,7 +268,8 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
         emission *= powerHeuristic(thePrd->pdf, lightPdf);
       }
       thePrd->radiance = emission;
-      thePrd->flags |= FLAG_TERMINATE;
+      thePrd->albedo   = emission;
+      thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
       return;
     }
   }
@@ -257,6 +286,7 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
     const float3 texColor = make_float3(tex2D(sysData.textures[0], state.texcoord.x, state.texcoord.y));
     state.albedo *= texColor;
   }
+  thePrd->albedo = state.albedo; // Optix7Gui closesthit.cu:247-249
 
   thePrd->flags = (thePrd->flags & ~FLAG_DIFFUSE) | FLAG_HIT | material.flags;
 
@@ -297,9 +327,12 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
 }
 
 // raygeneration.cu:42-149
-static float3 integrator(Oracle& o, PerRayData& prd, Hit* firstHit)
+static float3 integrator(Oracle& o, PerRayData& prd, Hit* firstHit, float3& albedo, float3& normal)
 {
   const SystemData& sysData = o.sys;
+  albedo = make_float3(0.0f);     // Optix7Gui raygeneration.cu:66-71
+  normal = make_float3(0.0f);
+  prd.normal = make_float3(0.0f);
   float4 absorptionStack[MATERIAL_STACK_SIZE];
   int stackIdx = MATERIAL_STACK_EMPTY;
   int depth = 0;
@@ -347,6 +380,24 @@ static float3 integrator(Oracle& o, PerRayData& prd, Hit* firstHit)
     }
 
     radiance += throughput * prd.radiance;
+
+    if (o.aov)
+    {
+      // Optix7Gui raygeneration.cu:125-164
+      if (!(prd.flags & FLAG_ALBEDO) && (prd.flags & (FLAG_DIFFUSE | FLAG_LIGHT)))
+      {
+        const float3 a = throughput * prd.albedo;
+        albedo = make_float3(clampf(a.x, 0.0f, 1.0f), clampf(a.y, 0.0f, 1.0f), clampf(a.z, 0.0f, 1.0f));
+        prd.flags |= FLAG_ALBEDO;
+      }
+      if (depth == 0 && h.instance >= 0) // FLAG_HIT of Optix7Gui's closest hit: any hit, lights included
+      {
+        const CameraDefinition& cam = sysData.cameraDefinitions[0];
+        normal = make_float3( dot(prd.normal, normalize(cam.U)),
+                              dot(prd.normal, normalize(cam.V)),
+                             -dot(prd.normal, normalize(cam.W)));
+      }
+    }
 
     if ((prd.flags & FLAG_TERMINATE) || prd.pdf <= 0.0f || isNull(prd.f_over_pdf))
     {
@@ -421,17 +472,30 @@ static void raygenPathTracer(Oracle& o, unsigned int lx, unsigned int ly)
 
   const unsigned int index = tiled ? (ly * (unsigned int) o.launchWidth + lx) : (ly * (unsigned int) sysData.resolution.x + launchColumn);
 
-  float3 radiance = integrator(o, prd, o.captureFirstHits ? &o.firstHits[index] : nullptr);
+  float3 albedo, normal;
+  float3 radiance = integrator(o, prd, o.captureFirstHits ? &o.firstHits[index] : nullptr, albedo, normal);
   rayTally().samples++;
 
   if (!(std::isnan(radiance.x) || std::isnan(radiance.y) || std::isnan(radiance.z)))
   {
     if (0 < sysData.iterationIndex)
     {
+      const float t = 1.0f / float(sysData.iterationIndex + 1);
       const float4 dst = o.output[index];
-      radiance = lerp(make_float3(dst), radiance, 1.0f / float(sysData.iterationIndex + 1));
+      radiance = lerp(make_float3(dst), radiance, t);
+      if (o.aov) // Optix7Gui raygeneration.cu:243-252
+      {
+        albedo = lerp(make_float3(o.aovAlbedo[index]), albedo, t);
+        normal = lerp(make_float3(o.aovNormal[index]), normal, t);
+        if (isNotNull(normal)) normal = normalize(normal);
+      }
     }
     o.output[index] = make_float4(radiance, 1.0f);
+    if (o.aov)
+    {
+      o.aovAlbedo[index] = make_float4(albedo, 1.0f);
+      o.aovNormal[index] = make_float4(normal, 0.0f);
+    }
   }
 }
 
@@ -589,6 +653,7 @@ int orc_set_state(OrcHandle o, const TwkDeviceState* s)
   else o->launchWidth = s->resolution[0];
   o->output.assign((size_t) o->launchWidth * s->resolution[1], make_float4(0.0f));
   o->firstHits.assign(o->output.size(), Hit{0, 0, 0, -1, -1});
+  if (o->aov) { o->aovAlbedo.assign(o->output.size(), make_float4(0.0f)); o->aovNormal = o->aovAlbedo; }
   return 0;
 }
 
@@ -691,6 +756,20 @@ int orc_clear_scene(OrcHandle o) { o->scene.clear(); return 0; }
 // 0 = brute force over all triangles (the definition), 1 = oracle BVH (same results, faster)
 int orc_set_trace_mode(OrcHandle o, int useBvh) { o->scene.useBvh = (useBvh != 0); return 0; }
 int orc_set_flatten_policy(OrcHandle o, int maxTriangles, int maxReferences) { o->scene.setFlattenPolicy(maxTriangles, maxReferences); return 0; } // ≙ twk_set_flatten_policy
+int orc_set_shader_variant(OrcHandle o, int variant) { o->shaderVariant = variant; return 0; } // ≙ twk_set_shader_variant
+int orc_enable_aov(OrcHandle o, int enable)                                                   // ≙ twk_enable_aov
+{
+  o->aov = (enable != 0);
+  if (o->aov) { o->aovAlbedo.assign(o->output.size(), make_float4(0.0f)); o->aovNormal = o->aovAlbedo; }
+  return 0;
+}
+int orc_read_aov(OrcHandle o, int which, float* rgba, size_t numFloats)                       // ≙ twk_read_aov
+{
+  const std::vector<float4>& src = (which == TWK_AOV_ALBEDO) ? o->aovAlbedo : o->aovNormal;
+  if (!o->aov || numFloats != src.size() * 4) { g_error = "orc_read_aov: AOVs off or size mismatch"; return 1; }
+  memcpy(rgba, src.data(), sizeof(float) * numFloats);
+  return 0;
+}
 int orc_capture_first_hits(OrcHandle o, int enable) { o->captureFirstHits = (enable != 0); return 0; }
 
 int orc_get_launch_width(OrcHandle o, int* w) { *w = o->launchWidth; return 0; }

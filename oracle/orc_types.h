@@ -27,12 +27,14 @@ enum
 static const unsigned int FLAG_HIT          = 0x00000001u;
 static const unsigned int FLAG_SHADOW       = 0x00000002u;
 static const unsigned int FLAG_DIFFUSE      = 0x00000004u;
+static const unsigned int FLAG_LIGHT        = 0x00000008u; // Optix7Gui per_ray_data.h:49 (0x4 there, DIFFUSE 0x8: only ever tested together)
 static const unsigned int FLAG_FRONTFACE    = 0x00000010u;
 static const unsigned int FLAG_THINWALLED   = 0x00000020u;
 static const unsigned int FLAG_TRANSMISSION = 0x00000100u;
 static const unsigned int FLAG_VOLUME       = 0x00001000u;
+static const unsigned int FLAG_ALBEDO       = 0x10000000u; // Optix7Gui per_ray_data.h:67
 static const unsigned int FLAG_TERMINATE    = 0x80000000u;
-static const unsigned int FLAG_CLEAR_MASK   = FLAG_DIFFUSE;
+static const unsigned int FLAG_CLEAR_MASK   = FLAG_DIFFUSE | FLAG_ALBEDO; // rtigo3 per_ray_data.h:71: DIFFUSE; Optix7Gui :76: DIFFUSE | ALBEDO (ALBEDO is never set without AOVs)
 
 // shaders/function_indices.h:34-60
 enum { NUM_LENS_SHADERS = 3, NUM_LIGHT_TYPES = 2 };
@@ -65,6 +67,8 @@ struct PerRayData
   float3 sigma_t;
   float  opacity;
   unsigned int seed;
+  float3 albedo;  // Optix7Gui per_ray_data.h:111: albedo for the denoiser's albedo buffer
+  float3 normal;  // Optix7Gui per_ray_data.h:114: shading normal for the denoiser's normal buffer
 };
 
 // shaders/material_definition.h:37-56 (texture objects become slot indices, 0 = none, else slot+1)

@@ -65,6 +65,7 @@ static inline float fmaxf3(const float3& a) { return fmaxf(fmaxf(a.x, a.y), a.z)
 // vector_math.h:620-623 (with the portable expf)
 static inline float3 expf3(const float3& v) { return {pm_expf(v.x), pm_expf(v.y), pm_expf(v.z)}; }
 
+static inline float clampf(float v, float lo, float hi) { return fmaxf(lo, fminf(v, hi)); } // vector_math.h:148-151
 static inline int clampi(int v, int lo, int hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
 
 } // namespace orc

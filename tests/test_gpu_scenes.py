@@ -341,3 +341,93 @@ def test_flatten_policy_two_level_soup_and_mixed(twk, orc, system, scene, res, i
     if "instances" in scene and policy == (4, 2):
         assert entered > 0, "the grid's shared meshes stay instanced under the default policy"
     dev.close()
+
+
+def test_c3_optix7gui_light_rule_and_rtigo3_rule(twk, orc):
+    """intro_07 is Optix7Gui's scene: scenes/system_intro_07.txt selects its closest-hit rule (a light ends the path on
+    either side, black on the back face, apps/Optix7Gui/shaders/closesthit.cu:189-226; rtigo3 lets a back-face hit
+    fall through to the light's BSDF, apps/rtigo3/shaders/closesthit.cu:192-222). Both rules against the oracle,
+    bit-identical, on intro_07 (where no path reaches the light's back and its material is black anyway: same image)."""
+    app, edit, textures = _intro07(twk, (128, 72))
+    assert app.info.shaderVariant == 1
+    images = {}
+    for variant in (1, 0):
+        dev, ref = _both(twk, orc, app, 0, textures=textures, material_edit=edit)
+        dev.setShaderVariant(variant)
+        ref.setShaderVariant(variant)
+        for it in range(3):
+            dev.render(it)
+            ref.render(it)
+        gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+        mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+        assert mism == 0, f"variant {variant}: {mism} pixels differ, max |diff| {np.abs(gpu - cpu).max()}"
+        images[variant] = gpu
+        dev.close()
+    assert np.array_equal(_bits(images[0]), _bits(images[1]))
+
+
+def test_light_back_face_rule_changes_the_image_when_the_light_material_is_not_black(twk, orc):
+    """The two apps' rules differ observably once a light's material scatters: a camera above the 1x1 area light of
+    `light 1` (facing down, y = 1.95) looks at its BACK. rtigo3 shades it with the light's BSDF (made diffuse here,
+    lit by the white environment), Optix7Gui ends the path black. Each variant bit-identical to the oracle."""
+    system = "\n".join(["resolution 96 64", "tileSize 8 8", "samplesSqrt 1", "miss 1", "light 1", "pathLengths 2 4", "epsilonFactor 500",
+                        "lensShader 0", "center 0 1.95 0", "camera 0.75 0.9 45 4"]) + "\n"  # theta 0.9: the camera is above the light
+    scene = "\n".join(["albedo 0.7 0.7 0.7", "material floor brdf_diffuse", "push", "scale 4 1 4", "model plane 1 1 1 floor", "pop"]) + "\n"
+    app = twk.Application(system_text=system, scene_text=scene)
+    light_material = [m for (_, _, m, l) in app.instances if l >= 0][0]
+
+    def diffuse_light(mats):
+        mats[light_material].indexBSDF = 0
+        mats[light_material].albedo[0] = mats[light_material].albedo[1] = mats[light_material].albedo[2] = 0.8
+
+    images = {}
+    for variant in (0, 1):
+        dev, ref = _both(twk, orc, app, 0, material_edit=diffuse_light)
+        dev.setShaderVariant(variant)
+        ref.setShaderVariant(variant)
+        for it in range(2):
+            dev.render(it)
+            ref.render(it)
+        gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+        assert np.array_equal(_bits(gpu), _bits(cpu)), f"variant {variant}"
+        images[variant] = gpu
+        dev.close()
+    black1 = (images[1][..., :3].max(axis=2) == 0.0)
+    lit0 = (images[0][..., :3].min(axis=2) > 0.05)
+    assert (black1 & lit0).sum() > 50, "Optix7Gui: the light's back is black; rtigo3: it reflects the environment through the light's BSDF"
+
+
+@pytest.mark.parametrize("scene", ["c3", "c2"])
+def test_denoiser_aovs_match_oracle(twk, orc, scene):
+    """Albedo and camera-space normal AOVs of Optix7Gui's integrator (raygeneration.cu:125-164,239-262): first diffuse /
+    light event's throughput-attenuated albedo, primary-hit shading normal, accumulated like the radiance. Both buffers
+    bit-identical to the oracle over four iterations; switching them on does not change the beauty image."""
+    if scene == "c3":
+        app, edit, textures = _intro07(twk, (128, 72))
+    else:
+        app, edit, textures = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (128, 72)), None, ()
+    plain, _ = _both(twk, orc, app, 0, textures=textures, material_edit=edit)
+    dev, ref = _both(twk, orc, app, 0, textures=textures, material_edit=edit)
+    dev.enableAov(True)
+    ref.enableAov(True)
+    dev.setLaunchBatch(3)  # 3 + 1: the running means cross a pass boundary
+    for it in range(4):
+        plain.render(it)
+        dev.render(it)
+        ref.render(it)
+    assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(ref.getOutputBufferHost()))
+    assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(plain.getOutputBufferHost()))
+    for which, name in ((0, "albedo"), (1, "normal")):
+        g, c = dev.readAov(which), ref.readAov(which)
+        mism = (_bits(g) != _bits(c)).any(axis=2).sum()
+        assert mism == 0, f"{name}: {mism} pixels differ, max |diff| {np.abs(g - c).max()}"
+    albedo, normal = dev.readAov(0), dev.readAov(1)
+    assert (albedo[..., :3] >= 0).all() and (albedo[..., :3] <= 1).all() and (albedo[..., 3] == 1).all()
+    n = np.linalg.norm(normal[..., :3], axis=2)
+    hit = n > 0
+    assert hit.mean() > 0.5 and np.allclose(n[hit], 1.0, atol=1e-5) and (normal[..., 3] == 0).all()
+    assert (normal[..., 2][hit] > -0.2).mean() > 0.95  # primary hits face the camera: +z in the right-handed camera space
+    with pytest.raises(twk.TwkError):
+        plain.readAov(0)  # not enabled on that handle
+    dev.close()
+    plain.close()

@@ -115,6 +115,10 @@ struct TwkDevice_t
   unsigned long long* d_stats = nullptr;
   int* d_spill = nullptr; size_t spillLanes = 0;
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
+  // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
+  bool aovEnabled = false; int shaderVariant = TWK_SHADERS_RTIGO3;
+  float4* d_pathAlbedo = nullptr; float4* d_pathNormal = nullptr; int aovPaths = 0;
+  float4* d_aovAlbedo = nullptr; float4* d_aovNormal = nullptr; int aovPixels = 0;
   bool captureFirstHits = false;
   bool statsEnabled = false;
   bool profileEnabled = false;
@@ -238,6 +242,9 @@ static void refreshParams(TwkDevice dev)
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   p.counters = dev->d_counters;
   p.stats = dev->statsEnabled ? dev->d_stats : nullptr;
+  p.shaderVariant = dev->shaderVariant;
+  p.pathAlbedo = dev->aovEnabled ? dev->d_pathAlbedo : nullptr; p.pathNormal = dev->aovEnabled ? dev->d_pathNormal : nullptr;
+  p.aovAlbedo  = dev->aovEnabled ? dev->d_aovAlbedo : nullptr;  p.aovNormal  = dev->aovEnabled ? dev->d_aovNormal : nullptr;
   p.firstHit = dev->captureFirstHits ? dev->d_firstHit : nullptr;
   p.firstHitInstance = dev->captureFirstHits ? dev->d_firstHitInstance : nullptr;
   p.traceStackSpill = dev->d_spill;
@@ -270,13 +277,33 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
   {
     freeDevice(dev->d_streamBlock);
     const size_t n = (size_t) numPaths;
-    // float4 streams: rayOrg[2], rayDir[2], hitRecord, shadowOrg, shadowDir, shadowPending, throughput, radiance, volumeStack[4] = 14
-    // 8-byte: seedFlags; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]
-    const size_t bytes = n * (14 * sizeof(float4) + sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
+    // float4 streams: rayOrg[2], rayDir[2], rayThroughput[2], hitRecord, shadowOrg, shadowDir, shadowPending, radiance, volumeStack[4] = 15
+    // 8-byte: raySeedFlags[2]; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]   → 280 bytes per path
+    const size_t bytes = n * (15 * sizeof(float4) + 2 * sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
     if (dev->streamBudgetBytes != 0 && bytes > dev->streamBudgetBytes)
       return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "path streams of " + std::to_string(bytes >> 20) + " MiB exceed TWK_STREAM_BUDGET_MB");
     HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
     dev->allocatedPaths = numPaths;
+  }
+  if (dev->aovEnabled)
+  {
+    if (dev->allocatedPaths > dev->aovPaths)
+    {
+      freeDevice(dev->d_pathAlbedo); freeDevice(dev->d_pathNormal); dev->aovPaths = 0;
+      HIP_TRY(hipMalloc(&dev->d_pathAlbedo, (size_t) dev->allocatedPaths * sizeof(float4)));
+      HIP_TRY(hipMalloc(&dev->d_pathNormal, (size_t) dev->allocatedPaths * sizeof(float4)));
+      dev->aovPaths = dev->allocatedPaths;
+    }
+    if (dev->allocatedPixels > dev->aovPixels)
+    {
+      freeDevice(dev->d_aovAlbedo); freeDevice(dev->d_aovNormal); dev->aovPixels = 0;
+      const size_t bytes = (size_t) dev->allocatedPixels * sizeof(float4);
+      HIP_TRY(hipMalloc(&dev->d_aovAlbedo, bytes));
+      HIP_TRY(hipMalloc(&dev->d_aovNormal, bytes));
+      HIP_TRY(hipMemsetAsync(dev->d_aovAlbedo, 0, bytes, dev->stream));
+      HIP_TRY(hipMemsetAsync(dev->d_aovNormal, 0, bytes, dev->stream));
+      dev->aovPixels = dev->allocatedPixels;
+    }
   }
   if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
   if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 24)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 24, dev->stream)); }
@@ -297,9 +324,9 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
   p.rayDir[0] = (float4*) take(16); p.rayDir[1] = (float4*) take(16);
   p.hitRecord = (float4*) take(16);
   p.shadowOrg = (float4*) take(16); p.shadowDir = (float4*) take(16); p.shadowPending = (float4*) take(16);
-  p.pathThroughput = (float4*) take(16); p.pathRadiance = (float4*) take(16);
+  p.rayThroughput[0] = (float4*) take(16); p.rayThroughput[1] = (float4*) take(16); p.pathRadiance = (float4*) take(16);
   p.volumeStack = (float4*) take(64);
-  p.pathSeedFlags = (uint2*) take(8);
+  p.raySeedFlags[0] = (uint2*) take(8); p.raySeedFlags[1] = (uint2*) take(8);
   p.rayPixel[0] = (unsigned int*) take(4); p.rayPixel[1] = (unsigned int*) take(4);
   p.hitInstance = (int*) take(4);
   p.shadowPixel = (unsigned int*) take(4);
@@ -406,7 +433,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count);
 
 static int flushPending(TwkDevice dev)
 {
-  // The streams of a pass take 344 bytes per pixel and iteration. When they do not fit in device memory the pass is
+  // The streams of a pass take 280 bytes per pixel and iteration. When they do not fit in device memory the pass is
   // cut in halves until they do (the image does not depend on how iterations are grouped) and the handle keeps the
   // smaller limit; only an allocation failure for a single iteration is reported.
   unsigned int first = dev->pendingFirst;
@@ -546,6 +573,7 @@ int twk_device_destroy(TwkDevice dev)
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
   freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
   freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
+  freeDevice(dev->d_pathAlbedo); freeDevice(dev->d_pathNormal); freeDevice(dev->d_aovAlbedo); freeDevice(dev->d_aovNormal);
   dev->builder.release();
   if (dev->stream) (void) hipStreamDestroy(dev->stream);
   delete dev;
@@ -955,6 +983,37 @@ int twk_read_output(TwkDevice dev, float* rgbaHost, size_t numFloats)
   if (numFloats != n * 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: buffer must hold launchWidth*height*4 floats");
   const float4* src = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   if (!src) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_read_output: nothing has been rendered");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  HIP_TRY(hipMemcpy(rgbaHost, src, n * sizeof(float4), hipMemcpyDeviceToHost));
+  return TWK_SUCCESS;
+}
+
+int twk_set_shader_variant(TwkDevice dev, int variant)
+{
+  int rc = activate(dev, "twk_set_shader_variant"); if (rc) return rc;
+  if (variant != TWK_SHADERS_RTIGO3 && variant != TWK_SHADERS_OPTIX7GUI) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_shader_variant: unknown variant");
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->shaderVariant = variant;
+  return TWK_SUCCESS;
+}
+
+int twk_enable_aov(TwkDevice dev, int enable)
+{
+  int rc = activate(dev, "twk_enable_aov"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->aovEnabled = (enable != 0);
+  if (dev->aovEnabled && dev->tailDepth > 0) { dev->aovEnabled = false; return twkSetError(TWK_ERROR_INVALID_STATE, "twk_enable_aov: not available together with the tail kernel (TWK_TAIL_DEPTH)"); }
+  return TWK_SUCCESS;
+}
+
+int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats)
+{
+  int rc = activate(dev, "twk_read_aov"); if (rc) return rc;
+  if (!rgbaHost || (which != TWK_AOV_ALBEDO && which != TWK_AOV_NORMAL)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_aov: bad arguments");
+  const size_t n = (size_t) dev->launchWidth * dev->state.resolution[1];
+  if (numFloats != n * 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_aov: buffer must hold launchWidth*height*4 floats");
+  const float4* src = (which == TWK_AOV_ALBEDO) ? dev->d_aovAlbedo : dev->d_aovNormal;
+  if (!dev->aovEnabled || !src || (size_t) dev->aovPixels < n) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_read_aov: nothing has been rendered with twk_enable_aov(1)");
   HIP_TRY(hipStreamSynchronize(dev->stream));
   HIP_TRY(hipMemcpy(rgbaHost, src, n * sizeof(float4), hipMemcpyDeviceToHost));
   return TWK_SUCCESS;

@@ -5,12 +5,14 @@
 // between kernels:
 //   ray queue      32 B  (origin.xyz, tmin | direction.xyz, tmax) + 4 B launch index
 //   hit record     16 B  (t, beta, gamma, triangle slot) + 4 B instance
-//   path state     per launch index: throughput+pdf 16 B, radiance 16 B, seed+flags 8 B, volume stack 64 B
+//   path state     in the ray queue (per slot): throughput+pdf 16 B, seed+flags 8 B — streamed with the ray;
+//                  per path: radiance 16 B, volume stack 64 B (touched only by additions / glass transmission)
 //   shadow queue   ray 32 B + 4 B launch index + pending contribution 16 B
 //   BVH2 node      64 B  (two child boxes + two child references)
 //   triangle       48 B  (three float4: vertex, w of the first = primitive index)
 #pragma once
 #include "device_math.h"
+#include "../../include/tweeker_hip.h" // TWK_SHADERS_*, TWK_FLATTEN_*
 
 namespace twk {
 
@@ -27,12 +29,14 @@ static const float DENOMINATOR_EPSILON = 1.0e-6f;
 #define TWK_FLAG_HIT          0x00000001u
 #define TWK_FLAG_SHADOW       0x00000002u
 #define TWK_FLAG_DIFFUSE      0x00000004u
+#define TWK_FLAG_LIGHT        0x00000008u // light or environment "hit" (Optix7Gui per_ray_data.h:49: 0x4 there, where DIFFUSE is 0x8; only tested together with DIFFUSE)
 #define TWK_FLAG_FRONTFACE    0x00000010u
 #define TWK_FLAG_THINWALLED   0x00000020u
 #define TWK_FLAG_TRANSMISSION 0x00000100u
 #define TWK_FLAG_VOLUME       0x00001000u
+#define TWK_FLAG_ALBEDO       0x10000000u // the path has written its denoiser albedo (Optix7Gui per_ray_data.h:67), persistent
 #define TWK_FLAG_TERMINATE    0x80000000u
-#define TWK_FLAG_CLEAR_MASK   TWK_FLAG_DIFFUSE
+#define TWK_FLAG_CLEAR_MASK   (TWK_FLAG_DIFFUSE | TWK_FLAG_ALBEDO) // rtigo3 per_ray_data.h:71 keeps DIFFUSE; Optix7Gui :76 also ALBEDO (never set without AOVs)
 
 // Path word packed next to the seed: bit 2 = FLAG_DIFFUSE of the last interaction (the only flag that
 // survives FLAG_CLEAR_MASK, raygeneration.cu:66), bits 8-15 depth, bits 16-18 volume stack index + 1.
@@ -167,10 +171,15 @@ struct LaunchParams
   float4* shadowDir;
   unsigned int* shadowPixel;
   float4* shadowPending; // throughput * NEE contribution
-  float4* pathThroughput; // xyz throughput, w pdf
+  float4* rayThroughput[2]; // per queue slot, next to the ray: xyz throughput, w pdf of the last BSDF sample
+  uint2*  raySeedFlags[2];  // per queue slot: LCG state, path word (FLAG_DIFFUSE, volume-stack index)
   float4* pathRadiance;
-  uint2*  pathSeedFlags;
   float4* volumeStack;    // [4][numPaths]
+  float4* pathAlbedo;     // denoiser AOVs (Optix7Gui raygeneration.cu:125-164), per path, nullptr when off: albedo of the first diffuse / light event
+  float4* pathNormal;     //   camera-space shading normal of the primary hit
+  float4* aovAlbedo;      // their running means per launch index (raygeneration.cu:239-262)
+  float4* aovNormal;
+  int     shaderVariant;  // TWK_SHADERS_RTIGO3 / TWK_SHADERS_OPTIX7GUI (include/tweeker_hip.h)
   float4* output;         // running mean, RGBA32F
   unsigned int* counters; // see CounterSlot
   unsigned long long* stats; // TwkLaunchStats as 7 u64, or nullptr

@@ -97,6 +97,9 @@ bool Application::loadSystemDescription(const std::string& text, std::string& er
       if (ok) { camera.phi = f[0]; camera.theta = f[1]; camera.fov = f[2]; camera.distance = f[3]; }
     }
     else if (key == "prefixScreenshot") { ok = (parser.restOfLine(prefixScreenshot) == TOKEN_ID); }
+    // Extension of the grammar (not in the reference): which app's closest-hit rule for light hits the scene was authored
+    // for — 0 rtigo3, 1 Optix7Gui (intro_07's app ends a path on a light's back face, closesthit.cu:189-226).
+    else if (key == "shaderVariant") { ok = readInt(parser, i[0]); if (ok) shaderVariant = (i[0] == 1) ? 1 : 0; }
     // tonemapper settings (Application.cpp:1244-1292), consumed by twk_tonemap / screenshot
     else if (key == "gamma")          { ok = readFloat(parser, tonemapper.gamma); }
     else if (key == "whitePoint")     { ok = readFloat(parser, tonemapper.whitePoint); }
@@ -140,6 +143,7 @@ std::string Application::systemDescription() const
   d << "pathLengths " << pathLengths[0] << " " << pathLengths[1] << std::endl;
   d << "epsilonFactor " << epsilonFactor << std::endl;
   d << "lensShader " << lensShader << std::endl;
+  if (shaderVariant != 0) d << "shaderVariant " << shaderVariant << std::endl;
   d << "center " << camera.center[0] << " " << camera.center[1] << " " << camera.center[2] << std::endl;
   d << "camera " << camera.phi << " " << camera.theta << " " << camera.fov << " " << camera.distance << std::endl;
   if (!prefixScreenshot.empty()) d << "prefixScreenshot " << prefixScreenshot << std::endl;

@@ -81,6 +81,7 @@ public:
   int   light         = 0;
   int   miss          = 1;
   int   lensShader    = 0;
+  int   shaderVariant = 0; // grammar extension "shaderVariant": 0 rtigo3, 1 Optix7Gui light-hit rule (include/tweeker_hip.h TWK_SHADERS_*)
   int   samplesSqrt   = 1;
   int   resolution[2] = {1, 1};
   int   tileSize[2]   = {8, 8};

@@ -77,6 +77,7 @@ int twk_app_info(TwkApp app, TwkAppInfo* info)
   info->phi = a.camera.phi; info->theta = a.camera.theta; info->fov = a.camera.fov; info->distance = a.camera.distance;
   info->numCameras = (int) a.cameras.size(); info->numLights = (int) a.lights.size(); info->numMaterials = (int) a.materials.size();
   info->numGeometries = (int) a.geometries.size(); info->numInstances = (int) a.instances.size();
+  info->shaderVariant = a.shaderVariant;
   return TWK_SUCCESS;
 }
 
@@ -151,6 +152,7 @@ int twk_app_init_device(TwkApp app, TwkDevice dev)
   int rc;
   TwkDeviceState state = a.deviceState();
   if ((rc = twk_set_state(dev, &state))) return rc;
+  if ((rc = twk_set_shader_variant(dev, a.shaderVariant))) return rc;
   if ((rc = twk_init_cameras(dev, a.cameras.data(), (int) a.cameras.size()))) return rc;
   if ((rc = twk_init_lights(dev, a.lights.data(), (int) a.lights.size()))) return rc;
   if ((rc = twk_init_materials(dev, a.materials.data(), (int) a.materials.size()))) return rc;

@@ -440,8 +440,9 @@ TWK_D unsigned int waveAppend(unsigned int* counter)
 
 // ---------------------------------------------------------------------------------------------
 // Shading of one path segment, shared by shadeKernel (wavefront bounces) and tailKernel (deep bounces):
-// miss or closest-hit shading, next-event estimation, then the integrator's loop tail. Path state is read from and
-// written back to the per-launch-index arrays; the continuation ray and the shadow ray are returned in registers.
+// miss or closest-hit shading, next-event estimation, then the integrator's loop tail. Throughput, pdf, RNG state
+// and flags come in and go out through `out` (they travel in the ray queue); radiance and the volume stack are
+// per-path arrays; the continuation ray and the shadow ray are returned in registers.
 struct ShadeOutput
 {
   bool  alive;       // the path continues with (nextPos, nextDir)
@@ -450,14 +451,16 @@ struct ShadeOutput
   V3    shadowDir;
   float shadowTmax;
   V3    pending;     // throughput * MIS-weighted next-event contribution
+  float4 throughputPdf; // in: the path's throughput.xyz and the pdf of its last BSDF sample; out (alive): the same after this bounce
+  uint2  seedFlags;     // in / out: LCG state, path word (TWK_PATH_* bits)
   unsigned int shadowSeed; // cutout scenes: RNG stream of the shadow ray's any-hit draws, forked from the path's seed
 };
 
 TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const float4& ro, const float4& rd,
                      const float4& hit, int instanceIndex, ShadeOutput& out)
 {
-  const float4 tp = p.pathThroughput[pixel];
-  const uint2  sf = p.pathSeedFlags[pixel];
+  const float4 tp = out.throughputPdf;
+  const uint2  sf = out.seedFlags;
   V3 throughput = v3(tp.x, tp.y, tp.z);
 
   PathPrd prd;
@@ -490,11 +493,12 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   bool wantShadow = false;
   V3 shadowDir = v3(0.0f), contribution = v3(0.0f);
   float shadowTmax = 0.0f;
+  V3 aovAlbedo = v3(0.0f), aovNormal = v3(0.0f); // prd.albedo / prd.normal of Optix7Gui's PerRayData (per_ray_data.h:111-114)
 
   if (instanceIndex < 0)
   {
     // ---- miss programs, miss.cu
-    if (p.miss == 0) { prd.radiance = v3(0.0f); }                                   // :41-52
+    if (p.miss == 0) { prd.radiance = v3(0.0f); }                                   // :41-52 (albedo 0)
     else if (p.miss == 2)                                                            // :75-109
     {
       const V3 R = prd.wi;
@@ -509,13 +513,15 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
         weightMIS = powerHeuristic(prd.pdf, pdfLight);
       }
       prd.radiance = emission * weightMIS;
+      aovAlbedo = emission;                                                          // Optix7Gui miss.cu:105-107
     }
     else                                                                             // :54-73
     {
       const float weightMIS = (prd.flags & TWK_FLAG_DIFFUSE) ? powerHeuristic(prd.pdf, 0.25f * kInvPi) : 1.0f;
       prd.radiance = v3(weightMIS);
+      aovAlbedo = v3(1.0f);                                                          // Optix7Gui miss.cu:67-69
     }
-    prd.flags |= TWK_FLAG_TERMINATE;
+    prd.flags |= TWK_FLAG_LIGHT | TWK_FLAG_TERMINATE;
   }
   else
   {
@@ -565,9 +571,32 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
       state.normal    = -state.normal;
     }
 
+    aovNormal = state.normal; // Optix7Gui closesthit.cu:183-185: the normal on the side the ray looks at
+
     bool lightHit = false;
-    if (0 <= inst.light && (prd.flags & TWK_FLAG_FRONTFACE))
+    if (0 <= inst.light && p.shaderVariant == TWK_SHADERS_OPTIX7GUI)
     {
+      // Optix7Gui closesthit.cu:189-226: a light ends the path whichever side is hit; black on the back face and edge-on
+      V3 emission = v3(0.0f);
+      const float cosTheta = dot(prd.wo, state.normalGeo);
+      if ((prd.flags & TWK_FLAG_FRONTFACE) && DENOMINATOR_EPSILON < cosTheta)
+      {
+        const DevLight& light = p.lights[inst.light];
+        emission = v3(light.emission[0], light.emission[1], light.emission[2]);
+        const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
+        if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
+        {
+          emission = emission * powerHeuristic(prd.pdf, lightPdf);
+        }
+      }
+      prd.radiance = emission;
+      aovAlbedo = emission;
+      prd.flags |= TWK_FLAG_HIT | TWK_FLAG_LIGHT | TWK_FLAG_TERMINATE;
+      lightHit = true;
+    }
+    else if (0 <= inst.light && (prd.flags & TWK_FLAG_FRONTFACE))
+    {
+      // rtigo3 closesthit.cu:192-222: only the lit side ends the path, a back-face hit falls through to the light's (black specular) BSDF
       const float cosTheta = dot(prd.wo, state.normalGeo);
       if (DENOMINATOR_EPSILON < cosTheta)
       {
@@ -579,7 +608,8 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
           emission = emission * powerHeuristic(prd.pdf, lightPdf);
         }
         prd.radiance = emission;
-        prd.flags |= TWK_FLAG_TERMINATE;
+        aovAlbedo = emission;
+        prd.flags |= TWK_FLAG_LIGHT | TWK_FLAG_TERMINATE;
         lightHit = true;
       }
     }
@@ -595,6 +625,7 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
         const V3 texColor = v3(tex2D(p.textures[0], state.texcoord.x, state.texcoord.y));
         state.albedo = state.albedo * texColor;
       }
+      aovAlbedo = state.albedo;                                                      // Optix7Gui closesthit.cu:247-249
 
       prd.flags = (prd.flags & ~TWK_FLAG_DIFFUSE) | TWK_FLAG_HIT | material.flags;
 
@@ -641,6 +672,26 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   }
 
 
+  unsigned int albedoWritten = 0u;
+  if (p.pathAlbedo != nullptr)
+  {
+    // Denoiser AOVs, Optix7Gui raygeneration.cu:125-164: the albedo of the first diffuse or light event, attenuated by
+    // the throughput up to it (after this segment's absorption, before this bounce's BSDF weight); the shading normal
+    // of the primary hit in a right-handed camera space.
+    if (!(prd.flags & TWK_FLAG_ALBEDO) && (prd.flags & (TWK_FLAG_DIFFUSE | TWK_FLAG_LIGHT)))
+    {
+      const V3 a = throughput * aovAlbedo;
+      p.pathAlbedo[pixel] = make_float4(fmaxf(0.0f, fminf(a.x, 1.0f)), fmaxf(0.0f, fminf(a.y, 1.0f)), fmaxf(0.0f, fminf(a.z, 1.0f)), 1.0f); // clamp(), vector_math.h:148-151
+      albedoWritten = TWK_FLAG_ALBEDO;
+    }
+    if (depth == 0 && instanceIndex >= 0)
+    {
+      const float* cam = p.camera;
+      const V3 U = normalize(v3(cam[3], cam[4], cam[5])), V = normalize(v3(cam[6], cam[7], cam[8])), W = normalize(v3(cam[9], cam[10], cam[11]));
+      p.pathNormal[pixel] = make_float4(dot(aovNormal, U), dot(aovNormal, V), -dot(aovNormal, W), 0.0f);
+    }
+  }
+
   out.wantShadow = wantShadow;
   out.shadowDir = shadowDir; out.shadowTmax = shadowTmax;
   out.pending = throughput * contribution;
@@ -685,8 +736,8 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
 
   if (alive)
   {
-    p.pathThroughput[pixel] = make_float4(throughput.x, throughput.y, throughput.z, prd.pdf);
-    p.pathSeedFlags[pixel]  = make_uint2(prd.seed, (prd.flags & TWK_FLAG_CLEAR_MASK) | ((unsigned int) (stackIdx + 1) << TWK_PATH_STACK_SHIFT));
+    out.throughputPdf = make_float4(throughput.x, throughput.y, throughput.z, prd.pdf);
+    out.seedFlags     = make_uint2(prd.seed, ((prd.flags | albedoWritten) & TWK_FLAG_CLEAR_MASK) | ((unsigned int) (stackIdx + 1) << TWK_PATH_STACK_SHIFT));
   }
   out.alive = alive;
   out.nextPos = prd.pos; out.nextDir = prd.wi;

@@ -83,8 +83,13 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 
   // integrator prologue (raygeneration.cu:53-62): black radiance, unit throughput, empty volume stack
   p.pathRadiance[index]   = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
-  p.pathThroughput[index] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-  p.pathSeedFlags[index]  = make_uint2(seed, 0u);
+  if (p.pathAlbedo != nullptr)
+  {
+    p.pathAlbedo[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // Optix7Gui raygeneration.cu:66-71: black, null vector
+    p.pathNormal[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  p.rayThroughput[0][index] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+  p.raySeedFlags[0][index]  = make_uint2(seed, 0u);
 
   // Inactive launch indices (tile columns beyond the image) still own a slot so that queue 0 is the
   // identity mapping; they carry tmax < tmin and never hit anything, and shade drops them.
@@ -95,8 +100,10 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// One thread per ray of queue (depth & 1): shadePath(), then append the continuation ray to queue ((depth + 1) & 1)
-// and the shadow ray (with the pending contribution) to the shadow queue.
+// One thread per ray of queue (depth & 1): shadePath(), then append the continuation ray — with the path's throughput,
+// pdf, RNG state and flags, which travel in the queue next to the ray so that every access of a bounce is a coalesced
+// stream (indexed by path they were 16-byte gathers after the first compaction) — to queue ((depth + 1) & 1) and the
+// shadow ray (with the pending contribution) to the shadow queue.
 //
 // Queue appends are aggregated per BLOCK (TWK_SHADE_BLOCK threads): every wave counts its appenders with a ballot, the
 // block sums the wave counts through LDS and one lane issues ONE returning atomic per queue per block iteration. With one atomic per
@@ -136,6 +143,8 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(
         pixel = p.rayPixel[q][slot];
         const float4 hit = p.hitRecord[slot];
         const int instanceIndex = p.hitInstance[slot];
+        out.throughputPdf = p.rayThroughput[q][slot];
+        out.seedFlags     = p.raySeedFlags[q][slot];
         shadePath(p, depth, pixel, ro, rd, hit, instanceIndex, out);
         if (p.stats != nullptr) { if (instanceIndex < 0) ++statMiss; else ++statHit; }
       }
@@ -173,6 +182,8 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(
       p.rayOrg[qn][n]   = make_float4(out.nextPos.x, out.nextPos.y, out.nextPos.z, p.sceneEpsilon);
       p.rayDir[qn][n]   = make_float4(out.nextDir.x, out.nextDir.y, out.nextDir.z, RT_DEFAULT_MAX);
       p.rayPixel[qn][n] = pixel;
+      p.rayThroughput[qn][n] = out.throughputPdf;
+      p.raySeedFlags[qn][n]  = out.seedFlags;
     }
     __syncthreads(); // waveCount / blockBase are rewritten by the next iteration
   }
@@ -199,25 +210,45 @@ __global__ void __launch_bounds__(256) accumulateKernel(LaunchParams p)
 {
   const unsigned int index = blockIdx.x * blockDim.x + threadIdx.x;
   if (index >= (unsigned int) p.numPixels) return;
+  const bool aov = (p.aovAlbedo != nullptr);
   float4 dst = p.output[index];
+  float4 dstAlbedo = aov ? p.aovAlbedo[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 dstNormal = aov ? p.aovNormal[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   bool touched = false;
   for (int s = 0; s < p.batchCount; ++s)
   {
-    const float4 r = p.pathRadiance[(size_t) s * p.numPixels + index];
+    const size_t path = (size_t) s * p.numPixels + index;
+    const float4 r = p.pathRadiance[path];
     if (r.w == 0.0f) continue; // launch index outside the image (tile padding): never written, like the early return at raygeneration.cu:180-183
     V3 radiance = v3(r.x, r.y, r.z);
     if (!(isnan(radiance.x) || isnan(radiance.y) || isnan(radiance.z)))
     {
       const unsigned int iteration = p.iterationIndex + (unsigned int) s;
+      V3 albedo = v3(0.0f), normal = v3(0.0f);
+      if (aov) { albedo = v3(p.pathAlbedo[path]); normal = v3(p.pathNormal[path]); }
       if (0 < iteration)
       {
-        radiance = lerp(v3(dst.x, dst.y, dst.z), radiance, 1.0f / float(iteration + 1));
+        const float t = 1.0f / float(iteration + 1);
+        radiance = lerp(v3(dst.x, dst.y, dst.z), radiance, t);
+        if (aov)
+        {
+          // Optix7Gui raygeneration.cu:243-252: same running mean; the mean normal is renormalised unless it vanished
+          albedo = lerp(v3(dstAlbedo), albedo, t);
+          normal = lerp(v3(dstNormal), normal, t);
+          if (isNotNull(normal)) normal = normalize(normal);
+        }
       }
       dst = make_float4(radiance.x, radiance.y, radiance.z, 1.0f);
+      dstAlbedo = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
+      dstNormal = make_float4(normal.x, normal.y, normal.z, 0.0f);
       touched = true;
     }
   }
-  if (touched) p.output[index] = dst;
+  if (touched)
+  {
+    p.output[index] = dst;
+    if (aov) { p.aovAlbedo[index] = dstAlbedo; p.aovNormal[index] = dstNormal; }
+  }
 }
 
 // compositor.cu:38-64 for every source device in one launch: tiles is [deviceCount][H][launchWidth].

@@ -36,7 +36,8 @@ tailKernel(LaunchParams p, int depth0)
 
   bool has = false, haveHit = false;
   unsigned int pixel = 0;
-  float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro, hit = ro;
+  float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro, hit = ro, throughputPdf = ro;
+  uint2 seedFlags = make_uint2(0u, 0u);
   int inst = -1, depth = depth0;
 
   for (;;)
@@ -65,6 +66,8 @@ tailKernel(LaunchParams p, int depth0)
           pixel = p.rayPixel[q][slot];
           hit = p.hitRecord[slot];
           inst = p.hitInstance[slot];
+          throughputPdf = p.rayThroughput[q][slot];
+          seedFlags = p.raySeedFlags[q][slot];
           depth = depth0;
           haveHit = true;
           has = (rd.w >= 0.0f); // inactive launch indices (tile padding) never get this deep, but stay safe
@@ -90,6 +93,7 @@ tailKernel(LaunchParams p, int depth0)
       }
 
       ShadeOutput out;
+      out.throughputPdf = throughputPdf; out.seedFlags = seedFlags;
       shadePath(p, depth, pixel, ro, rd, hit, inst, out);
       if (COUNT) { if (inst < 0) ++statMiss; else ++statHit; }
 
@@ -110,6 +114,7 @@ tailKernel(LaunchParams p, int depth0)
       {
         ro = make_float4(out.nextPos.x, out.nextPos.y, out.nextPos.z, p.sceneEpsilon);
         rd = make_float4(out.nextDir.x, out.nextDir.y, out.nextDir.z, RT_DEFAULT_MAX);
+        throughputPdf = out.throughputPdf; seedFlags = out.seedFlags;
         ++depth;
         haveHit = false;
       }

@@ -46,10 +46,9 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
   }
   else
   {
-    const unsigned int pixel = p.rayPixel[q][slot];
-    uint2 sf = p.pathSeedFlags[pixel];
+    uint2 sf = p.raySeedFlags[q][slot];
     draw = rng(sf.x);
-    p.pathSeedFlags[pixel] = sf;
+    p.raySeedFlags[q][slot] = sf;
   }
   if (!(opacity <= draw)) return false;
   if (isShadow) p.shadowOrg[slot - numClosest].w = res.t; else p.rayOrg[q][slot].w = res.t;

@@ -105,6 +105,20 @@ class Device:
         L.check(L.lib.twk_add_instance(self._h, int(idGeometry), t, int(idMaterial), int(idLight), C.byref(iid)))
         return iid.value
 
+    def setShaderVariant(self, variant):
+        """0 = rtigo3 (a light's back face reflects through its BSDF), 1 = Optix7Gui (any light hit ends the path)."""
+        L.check(L.lib.twk_set_shader_variant(self._h, int(variant)))
+
+    def enableAov(self, enable=True):
+        L.check(L.lib.twk_enable_aov(self._h, int(bool(enable))))
+
+    def readAov(self, which):
+        """Denoiser AOV running means: which = 0 albedo, 1 camera-space normal; float32 [height, launchWidth, 4]."""
+        h, w = self.state.resolution[1], self.launchWidth
+        out = np.empty((h, w, 4), dtype=np.float32)
+        L.check(L.lib.twk_read_aov(self._h, int(which), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(out.size)))
+        return out
+
     def setFlattenPolicy(self, maxTriangles, maxReferences):
         """Build option of the next build(): instances of geometries with <= maxTriangles triangles, or referenced by
         <= maxReferences instances, are intersected in world space in one single-level BVH; (0, 0) = pure two-level."""
