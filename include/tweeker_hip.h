@@ -202,6 +202,27 @@ int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12],
                      int idMaterial, int idLight, int* idInstance);                    /* ≙ createInstance Device.cpp:1427-1445 + hit record :1492-1532 */
 int twk_build(TwkDevice dev);                                                          /* ≙ createTLAS + createHitGroupRecords Device.cpp:1448-1532 */
 int twk_clear_scene(TwkDevice dev);
+/* Acceleration-structure quality of the next twk_build (≙ the buildFlags of accelBuildOptions, Device.cpp:1383-1389):
+ * TWK_BUILD_LBVH — Morton codes + radix tree, the fastest build; TWK_BUILD_SAH (default) — binned surface-area-heuristic
+ * top-down splits, fewer node visits per ray. Hit records do not depend on it (closest hit is order independent). */
+enum { TWK_BUILD_LBVH = 0, TWK_BUILD_SAH = 1 };
+int twk_set_build_quality(TwkDevice dev, int quality);
+
+/* What the last twk_build produced. SAH cost terms: over every bottom-level / flattened-instance tree, the sum of
+ * half-area(node) / half-area(root of its tree) over the inner nodes that survive the leaf collapse (sahInnerCost)
+ * and of half-area(leaf) / half-area(root) x triangles over its leaves (sahLeafCost): expected binary-node visits and
+ * triangle tests of a random ray that hits the root box, summed over `trees` trees. */
+typedef struct TwkBuildInfo
+{
+  int      quality;
+  int      trees;
+  double   sahInnerCost;
+  double   sahLeafCost;
+  double   buildMilliseconds; /* host wall time of twk_build, uploads included */
+  uint64_t triangleSlots, nodes, instances, flattenedInstances;
+} TwkBuildInfo;
+int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info);
+
 /* Flattening policy of the next twk_build (defaults TWK_FLATTEN_TRIANGLES, TWK_FLATTEN_REFERENCES; see there). */
 int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences);
 

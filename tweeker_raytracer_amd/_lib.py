@@ -73,6 +73,12 @@ class LaunchStats(C.Structure):
                 ("cachedNodesVisited", C.c_uint64)]
 
 
+class BuildInfo(C.Structure):
+    _fields_ = [("quality", C.c_int), ("trees", C.c_int), ("sahInnerCost", C.c_double), ("sahLeafCost", C.c_double),
+                ("buildMilliseconds", C.c_double), ("triangleSlots", C.c_uint64), ("nodes", C.c_uint64),
+                ("instances", C.c_uint64), ("flattenedInstances", C.c_uint64)]
+
+
 class AppInfo(C.Structure):
     _fields_ = [("strategy", C.c_int), ("devicesMask", C.c_int), ("light", C.c_int), ("miss", C.c_int),
                 ("lensShader", C.c_int), ("samplesSqrt", C.c_int), ("resolution", i2), ("tileSize", i2),
@@ -88,7 +94,7 @@ SYMBOLS = [
     "twk_last_error", "twk_abi_version", "twk_device_count", "twk_device_create", "twk_device_destroy",
     "twk_set_state", "twk_init_cameras", "twk_init_lights", "twk_init_materials", "twk_update_camera",
     "twk_update_light", "twk_update_material", "twk_init_texture", "twk_add_geometry", "twk_add_instance",
-    "twk_build", "twk_clear_scene", "twk_set_flatten_policy", "twk_launch", "twk_sync", "twk_set_launch_batch", "twk_reserve_launch_batch", "twk_get_launch_width", "twk_read_output",
+    "twk_build", "twk_clear_scene", "twk_set_flatten_policy", "twk_set_build_quality", "twk_get_build_info", "twk_launch", "twk_sync", "twk_set_launch_batch", "twk_reserve_launch_batch", "twk_get_launch_width", "twk_read_output",
     "twk_set_shader_variant", "twk_enable_aov", "twk_read_aov", "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_compositor", "twk_tonemap", "twk_profile_enable",
     "twk_profile_reset", "twk_profile_get", "twk_stats_enable", "twk_stats_get", "twk_stream_peak_gbps", "twk_gather_peak",
     "twk_debug_capture", "twk_debug_read_first_hits", "twk_trace_rays", "twk_debug_math",

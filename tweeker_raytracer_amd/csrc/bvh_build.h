@@ -30,11 +30,22 @@ public:
   hipError_t buildInstances(hipStream_t stream, const float4* hostLo, const float4* hostHi, const int* hostLeafPayload, int numInstances, BvhNode* outNodes, BvhNode* outWide, int nodeBase);
 
   void release();
+  // 0: Morton codes + Karras radix tree (LBVH); 1: binned-SAH top-down (bvh_sah.hip). Same refit / emission either way.
+  void setQuality(int q) { m_quality = (q != 0) ? 1 : 0; }
+  int  quality() const { return m_quality; }
+  // SAH cost terms of the tree built last (half-area relative to the root, summed over the final tree's inner nodes /
+  // over its leaf primitives), measured after every build.
+  double lastSahInner() const { return m_lastSahInner; }
+  double lastSahLeaf() const { return m_lastSahLeaf; }
   void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 4) ? 4 : n); } // count - 1 takes two bits of a leaf reference
 
 private:
   hipError_t reserve(int count);
   hipError_t buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase, int leafFlag);
+  hipError_t reserveSah(int count);
+  void releaseSah();
+  hipError_t buildSahTopology(hipStream_t stream, int count);
+  hipError_t accumulateSahCost(hipStream_t stream, int count);
 
   int m_capacity = 0;
   float4* m_primLo = nullptr; float4* m_primHi = nullptr;
@@ -46,6 +57,14 @@ private:
   float4* m_nodeLo = nullptr; float4* m_nodeHi = nullptr;
   unsigned int* m_bounds = nullptr;
   int* m_leafPayload = nullptr; // top level: leaf payload per instance
+  // binned-SAH builder scratch (bvh_sah.hip)
+  int  m_quality = 1;
+  int  m_sahCapacity = 0;
+  int* m_sahOrder[2] = {nullptr, nullptr}; int* m_sahSlot[2] = {nullptr, nullptr};
+  void* m_sahActive[2] = {nullptr, nullptr}; void* m_sahSmall = nullptr; void* m_sahSplit = nullptr;
+  unsigned int* m_sahCb = nullptr; unsigned int* m_sahBins = nullptr; unsigned int* m_sahFill = nullptr;
+  int* m_sahCounters = nullptr; double* m_sahCost = nullptr;
+  double m_lastSahInner = 0.0, m_lastSahLeaf = 0.0;
   void* m_sortTemp = nullptr; size_t m_sortBytes = 0;
 };
 

@@ -461,6 +461,7 @@ void BvhBuilder::release()
   m_left = m_right = m_innerParent = m_leafParent = nullptr; m_range = nullptr;
   m_tickets = nullptr; m_bounds = nullptr; m_sortTemp = nullptr; m_leafPayload = nullptr;
   m_capacity = 0;
+  releaseSah();
 }
 
 hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* outNodes, BvhNode* outWide, int nodeBase, int leafMode, int leafBase, int leafFlag)
@@ -474,13 +475,21 @@ hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* ou
     BVH_CHECK(hipMemsetAsync(m_keysOut, 0, sizeof(unsigned long long), stream));
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(mortonKeysKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, count, m_bounds, m_keysIn);
-  BVH_CHECK(rocprim::radix_sort_keys(m_sortTemp, m_sortBytes, m_keysIn, m_keysOut, (size_t) count, 0, 64, stream));
+  if (m_quality == 1)
+  {
+    BVH_CHECK(buildSahTopology(stream, count)); // binned-SAH splits: same arrays as the radix tree below
+  }
+  else
+  {
+    hipLaunchKernelGGL(mortonKeysKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, count, m_bounds, m_keysIn);
+    BVH_CHECK(rocprim::radix_sort_keys(m_sortTemp, m_sortBytes, m_keysIn, m_keysOut, (size_t) count, 0, 64, stream));
+    hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent, m_range);
+  }
   BVH_CHECK(hipMemsetAsync(m_tickets, 0, sizeof(unsigned int) * count, stream));
-  hipLaunchKernelGGL(radixTreeKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_left, m_right, m_innerParent, m_leafParent, m_range);
   hipLaunchKernelGGL(refitKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_primLo, m_primHi, m_left, m_right,
                      m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, outWide, nodeBase, leafMode, leafBase, m_maxLeaf, m_leafPayload, leafFlag);
-  return hipGetLastError();
+  BVH_CHECK(hipGetLastError());
+  return (leafMode == 0) ? accumulateSahCost(stream, count) : hipSuccess;
 }
 
 hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attributes, const unsigned int* indices, int numTriangles,

@@ -7,6 +7,7 @@
 #include "error_state.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +94,7 @@ struct TwkDevice_t
   bool twoLevel = true;                 // some instance is entered through the top level (else the soup is the whole scene)
   int  flattenMaxTriangles = TWK_FLATTEN_TRIANGLES, flattenMaxReferences = TWK_FLATTEN_REFERENCES;
   int  maxInstanceMaterial = -1, maxInstanceLight = -1; // largest indices the built scene's instances use
+  TwkBuildInfo buildInfo;
 
   // device memory
   float* d_camera = nullptr;
@@ -552,6 +554,8 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
   if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
+  memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
   if (const char* e = getenv("TWK_STREAM_BUDGET_MB")) { const long long mb = atoll(e); dev->streamBudgetBytes = (mb > 0) ? (size_t) mb << 20 : 0; }
   if (const char* e = getenv("TWK_BATCH")) { const int b = atoi(e); dev->batchMax = (b < 1) ? 1 : ((b > 64) ? 64 : b); }
   *out = dev;
@@ -763,10 +767,31 @@ int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences)
   return TWK_SUCCESS;
 }
 
+int twk_set_build_quality(TwkDevice dev, int quality)
+{
+  int rc = activate(dev, "twk_set_build_quality"); if (rc) return rc;
+  if (quality != TWK_BUILD_LBVH && quality != TWK_BUILD_SAH) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_build_quality: unknown quality");
+  dev->builder.setQuality(quality);
+  dev->built = false;
+  return TWK_SUCCESS;
+}
+
+int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info)
+{
+  if (!dev || !info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_build_info: NULL argument");
+  if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_get_build_info: twk_build has not been called");
+  *info = dev->buildInfo;
+  return TWK_SUCCESS;
+}
+
 int twk_build(TwkDevice dev)
 {
   int rc = activate(dev, "twk_build"); if (rc) return rc;
   if (dev->geometries.empty() || dev->instances.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: the scene has no geometry or no instance");
+  const auto buildStart = std::chrono::steady_clock::now();
+  TwkBuildInfo info;
+  memset(&info, 0, sizeof(info));
+  info.quality = dev->builder.quality();
   int maxMaterial = -1, maxLight = -1;
   for (const InstanceHost& inst : dev->instances)
   {
@@ -841,6 +866,7 @@ int twk_build(TwkDevice dev)
     if (!needsBlas[k]) continue;
     HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes + 12 * (size_t) g.attributeBase, dev->d_indices + g.indexBase, g.numTriangles,
                                         dev->d_nodes + g.nodeBase, dev->d_wideNodes + 2 * (size_t) g.nodeBase, g.nodeBase, dev->d_triangles, dev->d_shadeTriangles, g.triangleBase, g.rootBounds));
+    info.sahInnerCost += dev->builder.lastSahInner(); info.sahLeafCost += dev->builder.lastSahLeaf(); info.trees += 1;
   }
 
   // instance records (shading reads them for every hit, flattened or not)
@@ -876,6 +902,7 @@ int twk_build(TwkDevice dev)
       HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes, dev->d_indices, g.numTriangles,
                                           dev->d_nodes + flatNodeBase[i], dev->d_wideNodes + 2 * (size_t) flatNodeBase[i], flatNodeBase[i],
                                           dev->d_triangles, dev->d_shadeTriangles, flatTriangleBase[i], bounds, soup.ptr, dev->d_instances));
+      info.sahInnerCost += dev->builder.lastSahInner(); info.sahLeafCost += dev->builder.lastSahLeaf(); info.trees += 1;
       boxLo[i] = make_float4(bounds[0], bounds[1], bounds[2], 0.0f);
       boxHi[i] = make_float4(bounds[3], bounds[4], bounds[5], 0.0f);
       leafPayload[i] = ~flatNodeBase[i]; // child reference ~payload = the instance's root node: an inner reference
@@ -910,6 +937,9 @@ int twk_build(TwkDevice dev)
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
 
+  info.triangleSlots = numTris; info.nodes = numNodes; info.instances = (uint64_t) numInstances; info.flattenedInstances = (uint64_t) (numInstances - numEntered);
+  info.buildMilliseconds = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
+  dev->buildInfo = info;
   dev->twoLevel = (numEntered > 0);
   dev->maxInstanceMaterial = maxMaterial; dev->maxInstanceLight = maxLight;
   dev->totalNodes = numNodes; dev->totalTriangles = numTris;

@@ -119,6 +119,15 @@ class Device:
         L.check(L.lib.twk_read_aov(self._h, int(which), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(out.size)))
         return out
 
+    def setBuildQuality(self, quality):
+        """0 = LBVH (Morton + radix tree), 1 = binned SAH (default)."""
+        L.check(L.lib.twk_set_build_quality(self._h, int(quality)))
+
+    def buildInfo(self):
+        b = L.BuildInfo()
+        L.check(L.lib.twk_get_build_info(self._h, C.byref(b)))
+        return {name: getattr(b, name) for name, _ in L.BuildInfo._fields_}
+
     def setFlattenPolicy(self, maxTriangles, maxReferences):
         """Build option of the next build(): instances of geometries with <= maxTriangles triangles, or referenced by
         <= maxReferences instances, are intersected in world space in one single-level BVH; (0, 0) = pure two-level."""
