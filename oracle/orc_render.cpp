@@ -974,6 +974,50 @@ int orc_refract(const float i[3], const float n[3], float ior, float r[3])
   return ok ? 1 : 0;
 }
 
+// BSDF unit taps for the CPU property tests (tests/test_oracle_properties.py): many samples / evaluations of one BSDF at
+// a surface with shading normal = geometric normal `n` and tangent `t`, seen from `wo`, from the front (FLAG_FRONTFACE)
+// in vacuum. params: albedo.xyz, roughness.xy, ior. sample out per draw: wi.xyz, f_over_pdf.xyz, pdf, flags.
+static void tapSetup(const float* params, const float n[3], const float t[3], const float wo[3], MaterialDefinition& m, State& st, PerRayData& prd)
+{
+  memset(&m, 0, sizeof(m)); memset(&st, 0, sizeof(st)); memset(&prd, 0, sizeof(prd));
+  m.albedo = make_float3(params[0], params[1], params[2]); m.roughness = make_float2(params[3], params[4]); m.ior = params[5];
+  st.normalGeo = st.normal = make_float3(n[0], n[1], n[2]); st.tangent = make_float3(t[0], t[1], t[2]); st.albedo = m.albedo;
+  prd.wo = make_float3(wo[0], wo[1], wo[2]);
+  prd.ior = make_float2(1.0f);
+  prd.absorption_ior = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+  prd.flags = FLAG_FRONTFACE;
+}
+
+int orc_prop_bsdf_sample(int indexBSDF, const float* params, const float n[3], const float t[3], const float wo[3], unsigned int seed, int count, float* out8)
+{
+  MaterialDefinition m; State st; PerRayData prd;
+  for (int i = 0; i < count; ++i)
+  {
+    tapSetup(params, n, t, wo, m, st, prd);
+    prd.seed = seed;
+    callBsdfSample(indexBSDF, m, st, &prd);
+    seed = prd.seed;
+    float* o = out8 + 8 * (size_t) i;
+    o[0] = prd.wi.x; o[1] = prd.wi.y; o[2] = prd.wi.z; o[3] = prd.f_over_pdf.x; o[4] = prd.f_over_pdf.y; o[5] = prd.f_over_pdf.z; o[6] = prd.pdf;
+    memcpy(&o[7], &prd.flags, 4);
+  }
+  return 0;
+}
+
+int orc_prop_bsdf_eval(int indexBSDF, const float* params, const float n[3], const float t[3], const float wo[3], const float* wi3, int count, float* out4)
+{
+  MaterialDefinition m; State st; PerRayData prd;
+  tapSetup(params, n, t, wo, m, st, prd);
+  for (int i = 0; i < count; ++i)
+  {
+    const float4 r = callBsdfEval(indexBSDF, m, st, &prd, make_float3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]));
+    out4[4 * i] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
+  }
+  return 0;
+}
+
+float orc_fresnel_dielectric(float et, float cosIn) { return evaluateFresnelDielectric(et, cosIn); }
+
 int orc_tbn(const float tangentRef[3], const float n[3], float out9[9])
 {
   TBN t(make_float3(tangentRef[0], tangentRef[1], tangentRef[2]), make_float3(n[0], n[1], n[2]));
