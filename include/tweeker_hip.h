@@ -153,6 +153,7 @@ typedef struct TwkLaunchStats
   uint64_t triangleWaveSteps; /* wave-level iterations of the triangle test */
   uint64_t leafWaveSteps;     /* wave-level executions of the leaf / instance entry / instance exit step */
   uint64_t cachedNodesVisited; /* of nodesVisited: wide nodes served from the LDS top-of-tree cache, not from memory */
+  uint64_t droppedStackPushes; /* single-ray fallback traversal: pushes beyond its LDS + HBM stack (a truncated traversal); 0 on every scene tried */
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */

@@ -431,3 +431,37 @@ def test_denoiser_aovs_match_oracle(twk, orc, scene):
         plain.readAov(0)  # not enabled on that handle
     dev.close()
     plain.close()
+
+
+@pytest.mark.parametrize("system,scene,windows,iters", [
+    # C4 geometry at its full 1920x1080: box / sphere silhouettes on the floor; rough-glass box next to the glass sphere
+    ("system_rtigo3_geometry.txt", "scene_rtigo3_geometry.txt", [(580, 440, 644, 488), (900, 300, 964, 348), (1300, 420, 1364, 468)], 3),
+    # C4 instances at 1920x1080 (101 instances, two-level BVH under the default policy): the busiest window of the grid + a near-field one
+    ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", [(820, 600, 884, 648), (700, 200, 764, 248)], 3),
+    # C2: the floor under the glass sphere (caustic: paths through both glass interfaces, volume stack) and the sphere's
+    # lower rim, 8 iterations; the mirror sphere's reflection of the GGX wall
+    ("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", [(1040, 40, 1136, 120), (700, 250, 764, 298)], 8),
+])
+def test_full_size_windows(twk, orc, system, scene, windows, iters):
+    """Configurations at their FULL 1920x1080 frame on the device; the oracle renders windows of it (pixels are
+    independent given pixel and iteration). Bit-identical inside every window."""
+    app = load_app(twk, system, scene)
+    assert list(app.info.resolution) == [1920, 1080]
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    for it in range(iters):
+        dev.render(it)
+    gpu = dev.getOutputBufferHost()
+    assert np.isfinite(gpu).all()
+    for (x0, y0, x1, y1) in windows:
+        ref = orc.Oracle(miss=app.info.miss)
+        ref.loadApplication(app)
+        for it in range(iters):
+            ref.render(it, rect=(x0, y0, x1, y1), threads=8)
+        cpu = ref.getOutputBufferHost()
+        g, c = gpu[y0:y1, x0:x1], cpu[y0:y1, x0:x1]
+        assert c[..., :3].std() > 1e-3, "window shows something"
+        mism = (_bits(g) != _bits(c)).any(axis=2).sum()
+        assert mism == 0, f"window {(x0, y0, x1, y1)}: {mism} pixels differ, max |diff| {np.abs(g - c).max()}"
+        ref.close()
+    dev.close()

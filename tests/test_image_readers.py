@@ -211,3 +211,21 @@ def test_jpeg_reader_matches_libjpeg(twk, tmp_path):
     Image.fromarray(picture(32, 32)).save(p, progressive=True)
     with pytest.raises(twk.TwkError, match="progressive"):
         twk.load_image(p)
+
+
+def test_png_header_that_lies_about_its_size_is_refused_without_allocating(twk, tmp_path):
+    """IHDR is untrusted input: 60000 x 60000 RGBA16 (28.8 GB raw) over a 20-byte IDAT must be an error return, not an
+    allocation of the header's size (or a std::bad_alloc escaping through the C ABI)."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 16, 6, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\x00" * 9)) + chunk(b"IEND", b"")
+    path = tmp_path / "liar.png"
+    path.write_bytes(png)
+    with pytest.raises(twk.TwkError) as e:
+        twk.load_image(str(path))
+    assert "dimensions" in str(e.value) or "PNG" in str(e.value)

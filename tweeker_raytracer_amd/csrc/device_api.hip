@@ -510,6 +510,7 @@ const char* twk_last_error(void) { return g_lastError.c_str(); }
 int twk_abi_version(void) { return TWK_ABI_VERSION; }
 
 int twk_device_count(int* count)
+try
 {
   if (!count) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_device_count: NULL argument");
   *count = 0;
@@ -519,8 +520,10 @@ int twk_device_count(int* count)
   *count = n;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_device_count")
 
 int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int miss)
+try
 {
   if (!out) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_device_create: NULL out pointer");
   *out = nullptr;
@@ -561,8 +564,10 @@ int twk_device_create(TwkDevice* out, int ordinal, int index, int count, int mis
   *out = dev;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_device_create")
 
 int twk_device_destroy(TwkDevice dev)
+try
 {
   if (!dev) return TWK_SUCCESS;
   dev->pendingCount = 0; // recorded but never observed launches are dropped
@@ -583,8 +588,10 @@ int twk_device_destroy(TwkDevice dev)
   delete dev;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_device_destroy")
 
 int twk_set_state(TwkDevice dev, const TwkDeviceState* s)
+try
 {
   int rc = activate(dev, "twk_set_state"); if (rc) return rc;
   if (!s) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_state: NULL state");
@@ -610,8 +617,10 @@ int twk_set_state(TwkDevice dev, const TwkDeviceState* s)
   }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_set_state")
 
 int twk_init_cameras(TwkDevice dev, const TwkCameraDefinition* c, int count)
+try
 {
   int rc = activate(dev, "twk_init_cameras"); if (rc) return rc;
   if (!c || count < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_cameras: at least one camera is required");
@@ -621,8 +630,10 @@ int twk_init_cameras(TwkDevice dev, const TwkCameraDefinition* c, int count)
   HIP_TRY(hipMemcpyAsync(dev->d_camera, dev->cameras.data(), sizeof(TwkCameraDefinition), hipMemcpyHostToDevice, dev->stream)); // the lens shaders read cameraDefinitions[0]
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_init_cameras")
 
 int twk_update_camera(TwkDevice dev, int idCamera, const TwkCameraDefinition* c)
+try
 {
   int rc = activate(dev, "twk_update_camera"); if (rc) return rc;
   if (!c || idCamera < 0 || idCamera >= (int) dev->cameras.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_camera: bad camera id");
@@ -631,8 +642,10 @@ int twk_update_camera(TwkDevice dev, int idCamera, const TwkCameraDefinition* c)
   if (idCamera == 0) HIP_TRY(hipMemcpyAsync(dev->d_camera, dev->cameras.data(), sizeof(TwkCameraDefinition), hipMemcpyHostToDevice, dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_update_camera")
 
 int twk_init_lights(TwkDevice dev, const TwkLightDefinition* l, int count)
+try
 {
   int rc = activate(dev, "twk_init_lights"); if (rc) return rc;
   if (count < 0 || (count > 0 && !l)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_lights: bad arguments");
@@ -648,8 +661,10 @@ int twk_init_lights(TwkDevice dev, const TwkLightDefinition* l, int count)
   }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_init_lights")
 
 int twk_update_light(TwkDevice dev, int idLight, const TwkLightDefinition* l)
+try
 {
   int rc = activate(dev, "twk_update_light"); if (rc) return rc;
   if (!l || idLight < 0 || idLight >= (int) dev->lights.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_light: bad light id");
@@ -658,8 +673,10 @@ int twk_update_light(TwkDevice dev, int idLight, const TwkLightDefinition* l)
   HIP_TRY(hipMemcpyAsync(dev->d_lights + idLight, &dev->lights[idLight], sizeof(DevLight), hipMemcpyHostToDevice, dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_update_light")
 
 int twk_init_materials(TwkDevice dev, const TwkMaterialGUI* m, int count)
+try
 {
   int rc = activate(dev, "twk_init_materials"); if (rc) return rc;
   if (!m || count < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_materials: at least one material is required");
@@ -681,8 +698,10 @@ int twk_init_materials(TwkDevice dev, const TwkMaterialGUI* m, int count)
   HIP_TRY(hipMemcpyAsync(dev->d_materials, dev->materials.data(), sizeof(DevMaterial) * count, hipMemcpyHostToDevice, dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_init_materials")
 
 int twk_update_material(TwkDevice dev, int idMaterial, const TwkMaterialGUI* m)
+try
 {
   int rc = activate(dev, "twk_update_material"); if (rc) return rc;
   if (!m || idMaterial < 0 || idMaterial >= (int) dev->materials.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_update_material: bad material id");
@@ -692,8 +711,10 @@ int twk_update_material(TwkDevice dev, int idMaterial, const TwkMaterialGUI* m)
   HIP_TRY(hipMemcpyAsync(dev->d_materials + idMaterial, &dev->materials[idMaterial], sizeof(DevMaterial), hipMemcpyHostToDevice, dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_update_material")
 
 int twk_init_texture(TwkDevice dev, int slot, const float* rgba, int width, int height)
+try
 {
   int rc = activate(dev, "twk_init_texture"); if (rc) return rc;
   if (slot < 0 || slot > 2 || !rgba || width < 1 || height < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_init_texture: bad arguments");
@@ -717,14 +738,17 @@ int twk_init_texture(TwkDevice dev, int slot, const float* rgba, int width, int 
   }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_init_texture")
 
 int twk_clear_scene(TwkDevice dev)
+try
 {
   int rc = activate(dev, "twk_clear_scene"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->geometries.clear(); dev->instances.clear(); dev->built = false;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_clear_scene")
 
 int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, size_t numAttributes,
                      const unsigned int* indices, size_t numIndices, int* idGeometry)
@@ -745,6 +769,7 @@ int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, siz
 }
 
 int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12], int idMaterial, int idLight, int* idInstance)
+try
 {
   int rc = activate(dev, "twk_add_instance"); if (rc) return rc;
   if (!transform || idGeometry < 0 || idGeometry >= (int) dev->geometries.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_instance: bad geometry id");
@@ -757,8 +782,10 @@ int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12], i
   if (idInstance) *idInstance = (int) dev->instances.size() - 1;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_add_instance")
 
 int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences)
+try
 {
   int rc = activate(dev, "twk_set_flatten_policy"); if (rc) return rc;
   if (maxTriangles < 0 || maxReferences < 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_flatten_policy: limits must be >= 0");
@@ -766,8 +793,10 @@ int twk_set_flatten_policy(TwkDevice dev, int maxTriangles, int maxReferences)
   dev->built = false;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_set_flatten_policy")
 
 int twk_set_build_quality(TwkDevice dev, int quality)
+try
 {
   int rc = activate(dev, "twk_set_build_quality"); if (rc) return rc;
   if (quality != TWK_BUILD_LBVH && quality != TWK_BUILD_SAH) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_build_quality: unknown quality");
@@ -775,16 +804,20 @@ int twk_set_build_quality(TwkDevice dev, int quality)
   dev->built = false;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_set_build_quality")
 
 int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info)
+try
 {
   if (!dev || !info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_build_info: NULL argument");
   if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_get_build_info: twk_build has not been called");
   *info = dev->buildInfo;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_get_build_info")
 
 int twk_build(TwkDevice dev)
+try
 {
   int rc = activate(dev, "twk_build"); if (rc) return rc;
   if (dev->geometries.empty() || dev->instances.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: the scene has no geometry or no instance");
@@ -946,8 +979,10 @@ int twk_build(TwkDevice dev)
   dev->built = true;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_build")
 
 int twk_launch(TwkDevice dev, unsigned int iterationIndex)
+try
 {
   int rc = activate(dev, "twk_launch", false); if (rc) return rc;
   if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: twk_set_state has not been called (samplesSqrt 0, Device.cpp:293)");
@@ -973,8 +1008,10 @@ int twk_launch(TwkDevice dev, unsigned int iterationIndex)
   if (dev->pendingCount >= limit) return flushPending(dev);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_launch")
 
 int twk_set_launch_batch(TwkDevice dev, int iterations)
+try
 {
   int rc = activate(dev, "twk_set_launch_batch"); if (rc) return rc;
   if (iterations < 1 || iterations > 64) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_launch_batch: 1..64 iterations per pass");
@@ -982,30 +1019,38 @@ int twk_set_launch_batch(TwkDevice dev, int iterations)
   dev->batchMax = iterations;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_set_launch_batch")
 
 int twk_reserve_launch_batch(TwkDevice dev, int iterations)
+try
 {
   int rc = activate(dev, "twk_reserve_launch_batch"); if (rc) return rc;
   if (iterations < 1 || iterations > 64) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_reserve_launch_batch: 1..64 iterations per pass");
   if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_reserve_launch_batch: twk_set_state first");
   return ensureStreams(dev, iterations);
 }
+TWK_CATCH("twk_reserve_launch_batch")
 
 int twk_sync(TwkDevice dev)
+try
 {
   int rc = activate(dev, "twk_sync"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_sync")
 
 int twk_get_launch_width(TwkDevice dev, int* launchWidth)
+try
 {
   if (!dev || !launchWidth) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_launch_width: NULL argument");
   *launchWidth = dev->launchWidth;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_get_launch_width")
 
 int twk_read_output(TwkDevice dev, float* rgbaHost, size_t numFloats)
+try
 {
   int rc = activate(dev, "twk_read_output"); if (rc) return rc;
   if (!rgbaHost) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: NULL buffer");
@@ -1017,8 +1062,10 @@ int twk_read_output(TwkDevice dev, float* rgbaHost, size_t numFloats)
   HIP_TRY(hipMemcpy(rgbaHost, src, n * sizeof(float4), hipMemcpyDeviceToHost));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_read_output")
 
 int twk_set_shader_variant(TwkDevice dev, int variant)
+try
 {
   int rc = activate(dev, "twk_set_shader_variant"); if (rc) return rc;
   if (variant != TWK_SHADERS_RTIGO3 && variant != TWK_SHADERS_OPTIX7GUI) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_shader_variant: unknown variant");
@@ -1026,8 +1073,10 @@ int twk_set_shader_variant(TwkDevice dev, int variant)
   dev->shaderVariant = variant;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_set_shader_variant")
 
 int twk_enable_aov(TwkDevice dev, int enable)
+try
 {
   int rc = activate(dev, "twk_enable_aov"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
@@ -1035,8 +1084,10 @@ int twk_enable_aov(TwkDevice dev, int enable)
   if (dev->aovEnabled && dev->tailDepth > 0) { dev->aovEnabled = false; return twkSetError(TWK_ERROR_INVALID_STATE, "twk_enable_aov: not available together with the tail kernel (TWK_TAIL_DEPTH)"); }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_enable_aov")
 
 int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats)
+try
 {
   int rc = activate(dev, "twk_read_aov"); if (rc) return rc;
   if (!rgbaHost || (which != TWK_AOV_ALBEDO && which != TWK_AOV_NORMAL)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_aov: bad arguments");
@@ -1048,8 +1099,10 @@ int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats)
   HIP_TRY(hipMemcpy(rgbaHost, src, n * sizeof(float4), hipMemcpyDeviceToHost));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_read_aov")
 
 int twk_get_output_device_pointer(TwkDevice dev, void** dptr, size_t* bytes)
+try
 {
   int rc = activate(dev, "twk_get_output_device_pointer"); if (rc) return rc;
   if (!dptr) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_output_device_pointer: NULL argument");
@@ -1059,8 +1112,10 @@ int twk_get_output_device_pointer(TwkDevice dev, void** dptr, size_t* bytes)
   if (bytes) *bytes = (size_t) dev->launchWidth * dev->state.resolution[1] * sizeof(float4);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_get_output_device_pointer")
 
 int twk_set_output_device_pointer(TwkDevice dev, void* dptr, size_t bytes)
+try
 {
   int rc = activate(dev, "twk_set_output_device_pointer"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
@@ -1070,8 +1125,10 @@ int twk_set_output_device_pointer(TwkDevice dev, void* dptr, size_t bytes)
   dev->d_outputExternal = static_cast<float4*>(dptr); dev->outputExternalBytes = bytes;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_set_output_device_pointer")
 
 int twk_compositor(TwkDevice dev, const void* tiles, void* output)
+try
 {
   int rc = activate(dev, "twk_compositor"); if (rc) return rc;
   if (!tiles || !output) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_compositor: NULL buffer");
@@ -1081,8 +1138,10 @@ int twk_compositor(TwkDevice dev, const void* tiles, void* output)
   HIP_TRY(hipGetLastError());
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_compositor")
 
 int twk_tonemap(TwkDevice dev, const TwkTonemapper* tm, const void* rgbaDevice, size_t numPixels, unsigned char* rgb8Host)
+try
 {
   int rc = activate(dev, "twk_tonemap"); if (rc) return rc;
   if (!tm || !rgb8Host) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_tonemap: NULL argument");
@@ -1103,41 +1162,51 @@ int twk_tonemap(TwkDevice dev, const TwkTonemapper* tm, const void* rgbaDevice, 
   HIP_TRY(hipStreamSynchronize(dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_tonemap")
 
 // ---- measurement ------------------------------------------------------------------------------
 int twk_profile_enable(TwkDevice dev, int enable)
+try
 {
   int rc = activate(dev, "twk_profile_enable"); if (rc) return rc;
   if ((rc = collectTimed(dev))) return rc;
   dev->profileEnabled = (enable != 0);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_profile_enable")
 
 int twk_profile_reset(TwkDevice dev)
+try
 {
   int rc = activate(dev, "twk_profile_reset"); if (rc) return rc;
   if ((rc = collectTimed(dev))) return rc;
   for (int k = 0; k < TWK_KERNEL_COUNT; ++k) { dev->profileMs[k] = 0.0f; dev->profileLaunches[k] = 0; }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_profile_reset")
 
 int twk_profile_get(TwkDevice dev, float ms[TWK_KERNEL_COUNT], int launches[TWK_KERNEL_COUNT])
+try
 {
   int rc = activate(dev, "twk_profile_get"); if (rc) return rc;
   if ((rc = collectTimed(dev))) return rc;
   for (int k = 0; k < TWK_KERNEL_COUNT; ++k) { if (ms) ms[k] = dev->profileMs[k]; if (launches) launches[k] = dev->profileLaunches[k]; }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_profile_get")
 
 int twk_stats_enable(TwkDevice dev, int enable)
+try
 {
   int rc = activate(dev, "twk_stats_enable"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->statsEnabled = (enable != 0);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_stats_enable")
 
 int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
+try
 {
   int rc = activate(dev, "twk_stats_get"); if (rc) return rc;
   if (!stats) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_stats_get: NULL argument");
@@ -1150,12 +1219,14 @@ int twk_stats_get(TwkDevice dev, TwkLaunchStats* stats, int reset)
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
   stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
   stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
-  stats->cachedNodesVisited = h[16];
+  stats->cachedNodesVisited = h[16]; stats->droppedStackPushes = h[17];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_stats_get")
 
 int twk_stream_peak_gbps(TwkDevice dev, size_t bytes, int repeats, float* gbps)
+try
 {
   int rc = activate(dev, "twk_stream_peak_gbps"); if (rc) return rc;
   if (!gbps || bytes < 4096 || repeats < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_stream_peak_gbps: bad arguments");
@@ -1179,8 +1250,10 @@ int twk_stream_peak_gbps(TwkDevice dev, size_t bytes, int repeats, float* gbps)
   *gbps = (float) (2.0 * (double) (n * sizeof(float4)) * repeats / ((double) ms * 1.0e-3) / 1.0e9);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_stream_peak_gbps")
 
 int twk_gather_peak(TwkDevice dev, size_t tableBytes, float* gigaLaneLoadsPerSecond)
+try
 {
   int rc = activate(dev, "twk_gather_peak"); if (rc) return rc;
   if (!gigaLaneLoadsPerSecond || tableBytes < 128 * 1024 || tableBytes > ((size_t) 1 << 36)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_gather_peak: bad arguments");
@@ -1204,17 +1277,21 @@ int twk_gather_peak(TwkDevice dev, size_t tableBytes, float* gigaLaneLoadsPerSec
   *gigaLaneLoadsPerSecond = (float) ((double) blocks * 256.0 * steps * 8.0 / ((double) ms * 1.0e-3) / 1.0e9);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_gather_peak")
 
 // ---- parity taps ------------------------------------------------------------------------------
 int twk_debug_capture(TwkDevice dev, int enable)
+try
 {
   int rc = activate(dev, "twk_debug_capture"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->captureFirstHits = (enable != 0);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_debug_capture")
 
 int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma, int* instPrim, size_t numPixels)
+try
 {
   int rc = activate(dev, "twk_debug_read_first_hits"); if (rc) return rc;
   const size_t n = (size_t) dev->launchWidth * dev->state.resolution[1];
@@ -1233,8 +1310,10 @@ int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma, int* instPrim, s
   }
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_debug_read_first_hits")
 
 int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids)
+try
 {
   int rc = activate(dev, "twk_trace_rays"); if (rc) return rc;
   if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_trace_rays: twk_build has not been called");
@@ -1256,8 +1335,10 @@ int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit,
   HIP_TRY(hipStreamSynchronize(dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_trace_rays")
 
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n)
+try
 {
   int rc = activate(dev, "twk_debug_math"); if (rc) return rc;
   if (op < 0 || op > 9 || !x || !out || ((op == 3 || op == 9) && !y)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_math: bad arguments");
@@ -1273,5 +1354,6 @@ int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float*
   HIP_TRY(hipStreamSynchronize(dev->stream));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_debug_math")
 
 } // extern "C"

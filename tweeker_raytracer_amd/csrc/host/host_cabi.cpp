@@ -42,6 +42,7 @@ static int copyMeshOut(const TriangleMesh& mesh, TwkTriangleAttributes* attr, si
 extern "C" {
 
 int twk_app_create_from_strings(TwkApp* out, const char* systemDescription, const char* sceneDescription)
+try
 {
   if (!out || !systemDescription || !sceneDescription) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_create: NULL argument");
   *out = nullptr;
@@ -52,8 +53,10 @@ int twk_app_create_from_strings(TwkApp* out, const char* systemDescription, cons
   *out = a;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_create_from_strings")
 
 int twk_app_create(TwkApp* out, const char* systemDescriptionFile, const char* sceneDescriptionFile)
+try
 {
   if (!out || !systemDescriptionFile || !sceneDescriptionFile) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_create: NULL argument");
   *out = nullptr;
@@ -62,10 +65,12 @@ int twk_app_create(TwkApp* out, const char* systemDescriptionFile, const char* s
   if (!readTextFile(sceneDescriptionFile, scene)) return twkSetError(TWK_ERROR_IO, std::string("failed to open scene description file ") + sceneDescriptionFile);
   return twk_app_create_from_strings(out, sys.c_str(), scene.c_str());
 }
+TWK_CATCH("twk_app_create")
 
 int twk_app_destroy(TwkApp app) { delete app; return TWK_SUCCESS; }
 
 int twk_app_info(TwkApp app, TwkAppInfo* info)
+try
 {
   if (!app || !info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_info: NULL argument");
   const Application& a = app->app;
@@ -80,51 +85,65 @@ int twk_app_info(TwkApp app, TwkAppInfo* info)
   info->shaderVariant = a.shaderVariant;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_info")
 
 int twk_app_set_resolution(TwkApp app, int width, int height)
+try
 {
   if (!app) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_set_resolution: NULL app");
   app->app.setResolution(width, height);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_set_resolution")
 
 int twk_app_get_state(TwkApp app, TwkDeviceState* state)
+try
 {
   if (!app || !state) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_state: NULL argument");
   *state = app->app.deviceState();
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_state")
 
 int twk_app_get_cameras(TwkApp app, TwkCameraDefinition* out, int capacity)
+try
 {
   if (!app || !out || capacity < (int) app->app.cameras.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_cameras: bad arguments");
   memcpy(out, app->app.cameras.data(), sizeof(TwkCameraDefinition) * app->app.cameras.size());
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_cameras")
 
 int twk_app_get_lights(TwkApp app, TwkLightDefinition* out, int capacity)
+try
 {
   if (!app || capacity < (int) app->app.lights.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_lights: bad arguments");
   if (!app->app.lights.empty()) memcpy(out, app->app.lights.data(), sizeof(TwkLightDefinition) * app->app.lights.size());
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_lights")
 
 int twk_app_get_materials(TwkApp app, TwkMaterialGUI* out, int capacity)
+try
 {
   if (!app || !out || capacity < (int) app->app.materials.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_materials: bad arguments");
   memcpy(out, app->app.materials.data(), sizeof(TwkMaterialGUI) * app->app.materials.size());
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_materials")
 
 int twk_app_get_geometry_sizes(TwkApp app, int idGeometry, size_t* numAttributes, size_t* numIndices)
+try
 {
   if (!app || idGeometry < 0 || idGeometry >= (int) app->app.geometries.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_geometry_sizes: bad geometry id");
   *numAttributes = app->app.geometries[idGeometry]->mesh.attributes.size();
   *numIndices    = app->app.geometries[idGeometry]->mesh.indices.size();
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_geometry_sizes")
 
 int twk_app_get_geometry(TwkApp app, int idGeometry, TwkTriangleAttributes* attributes, unsigned int* indices)
+try
 {
   if (!app || idGeometry < 0 || idGeometry >= (int) app->app.geometries.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_geometry: bad geometry id");
   const TriangleMesh& mesh = app->app.geometries[idGeometry]->mesh;
@@ -132,8 +151,10 @@ int twk_app_get_geometry(TwkApp app, int idGeometry, TwkTriangleAttributes* attr
   if (indices)    memcpy(indices, mesh.indices.data(), sizeof(unsigned int) * mesh.indices.size());
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_geometry")
 
 int twk_app_get_instance(TwkApp app, int idInstance, int* idGeometry, float transform[12], int* idMaterial, int* idLight)
+try
 {
   if (!app || idInstance < 0 || idInstance >= (int) app->app.instances.size()) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_instance: bad instance id");
   const FlatInstance& fi = app->app.instances[idInstance];
@@ -143,9 +164,11 @@ int twk_app_get_instance(TwkApp app, int idInstance, int* idGeometry, float tran
   if (idLight)    *idLight = fi.light;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_instance")
 
 // ≙ Application.cpp:303 (initState) and :328-332 (initCameras/Lights/Materials/Scene)
 int twk_app_init_device(TwkApp app, TwkDevice dev)
+try
 {
   if (!app || !dev) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_init_device: NULL argument");
   const Application& a = app->app;
@@ -169,8 +192,10 @@ int twk_app_init_device(TwkApp app, TwkDevice dev)
   }
   return twk_build(dev);
 }
+TWK_CATCH("twk_app_init_device")
 
 int twk_app_system_description(TwkApp app, char* out, size_t capacity, size_t* length)
+try
 {
   if (!app) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_system_description: NULL argument");
   const std::string s = app->app.systemDescription();
@@ -180,17 +205,21 @@ int twk_app_system_description(TwkApp app, char* out, size_t capacity, size_t* l
   memcpy(out, s.c_str(), s.size() + 1);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_system_description")
 
 int twk_app_get_tonemapper(TwkApp app, TwkTonemapper* tm)
+try
 {
   if (!app || !tm) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_tonemapper: NULL argument");
   *tm = app->app.tonemapper;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_tonemapper")
 
 // ≙ Application::screenshot's path (Application.cpp:2235-2239,2256,2303) with getDateTime's Linux branch (:1927-2008),
 // which prints tm_year (years since 1900) and tm_mon (0-based) as they are and "000" for the milliseconds.
 int twk_app_screenshot_path(TwkApp app, int tonemap, char* out, size_t capacity)
+try
 {
   if (!app || !out) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_screenshot_path: NULL argument");
   time_t rawtime;
@@ -217,8 +246,10 @@ int twk_app_screenshot_path(TwkApp app, int tonemap, char* out, size_t capacity)
   memcpy(out, s.c_str(), s.size() + 1);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_screenshot_path")
 
 int twk_load_image(const char* path, int* width, int* height, float* rgba, size_t capacityFloats)
+try
 {
   if (!path || !width || !height) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_load_image: NULL argument");
   int w = 0, h = 0;
@@ -231,8 +262,10 @@ int twk_load_image(const char* path, int* width, int* height, float* rgba, size_
   memcpy(rgba, pixels.data(), pixels.size() * sizeof(float));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_load_image")
 
 int twk_app_get_environment(TwkApp app, char* out, size_t capacity)
+try
 {
   if (!app || !out || capacity == 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_app_get_environment: NULL argument");
   const std::string& s = app->app.environment;
@@ -240,52 +273,68 @@ int twk_app_get_environment(TwkApp app, char* out, size_t capacity)
   memcpy(out, s.c_str(), s.size() + 1);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_app_get_environment")
 
 int twk_write_png_rgb8(const char* path, int width, int height, const unsigned char* rgb8, int bottomUp)
+try
 {
   if (!path || !rgb8 || width <= 0 || height <= 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_write_png_rgb8: bad arguments");
   std::string error;
   if (!writePngRgb8(path, width, height, rgb8, bottomUp != 0, error)) return twkSetError(TWK_ERROR_IO, error);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_write_png_rgb8")
 
 int twk_write_hdr_rgba32f(const char* path, int width, int height, const float* rgba, int bottomUp)
+try
 {
   if (!path || !rgba || width <= 0 || height <= 0) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_write_hdr_rgba32f: bad arguments");
   std::string error;
   if (!writeHdrRgba32f(path, width, height, rgba, bottomUp != 0, error)) return twkSetError(TWK_ERROR_IO, error);
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_write_hdr_rgba32f")
 
 int twk_mesh_plane(unsigned int tessU, unsigned int tessV, unsigned int upAxis, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx)
+try
 {
   if (tessU < 1 || tessV < 1 || upAxis > 2) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_mesh_plane: tessellation must be >= 1, upAxis 0..2");
   TriangleMesh m; makePlane(m, tessU, tessV, upAxis); return copyMeshOut(m, attr, numAttr, idx, numIdx);
 }
+TWK_CATCH("twk_mesh_plane")
 
 int twk_mesh_box(TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx)
+try
 {
   TriangleMesh m; makeBox(m); return copyMeshOut(m, attr, numAttr, idx, numIdx);
 }
+TWK_CATCH("twk_mesh_box")
 
 int twk_mesh_sphere(unsigned int tessU, unsigned int tessV, float radius, float maxTheta, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx)
+try
 {
   if (tessU < 3 || tessV < 3) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_mesh_sphere: tessellation must be >= 3");
   TriangleMesh m; makeSphere(m, tessU, tessV, radius, maxTheta); return copyMeshOut(m, attr, numAttr, idx, numIdx);
 }
+TWK_CATCH("twk_mesh_sphere")
 
 int twk_mesh_torus(unsigned int tessU, unsigned int tessV, float innerRadius, float outerRadius, TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx)
+try
 {
   if (tessU < 3 || tessV < 3) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_mesh_torus: tessellation must be >= 3");
   TriangleMesh m; makeTorus(m, tessU, tessV, innerRadius, outerRadius); return copyMeshOut(m, attr, numAttr, idx, numIdx);
 }
+TWK_CATCH("twk_mesh_torus")
 
 int twk_mesh_parallelogram(const float position[3], const float vecU[3], const float vecV[3], const float normal[3], TwkTriangleAttributes* attr, size_t* numAttr, unsigned int* idx, size_t* numIdx)
+try
 {
   TriangleMesh m; makeParallelogram(m, position, vecU, vecV, normal); return copyMeshOut(m, attr, numAttr, idx, numIdx);
 }
+TWK_CATCH("twk_mesh_parallelogram")
 
 int twk_camera_frustum(const float center[3], float phi, float theta, float fov, float distance, float aspect, TwkCameraDefinition* out)
+try
 {
   if (!center || !out) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_camera_frustum: NULL argument");
   OrbitCamera c;
@@ -294,9 +343,11 @@ int twk_camera_frustum(const float center[3], float phi, float theta, float fov,
   *out = c.frustum();
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_camera_frustum")
 
 // ≙ calculateTileShift (Device.cpp:1172-1189) + distribute() (raygeneration.cu:152-164)
 int twk_tile_column(int launchX, int launchY, const int tileSize[2], int deviceCount, int deviceIndex, int* pixelX)
+try
 {
   if (!tileSize || !pixelX || deviceCount < 1 || tileSize[0] < 1 || tileSize[1] < 1 ||
       (tileSize[0] & (tileSize[0] - 1)) || (tileSize[1] & (tileSize[1] - 1)))
@@ -309,8 +360,10 @@ int twk_tile_column(int launchX, int launchY, const int tileSize[2], int deviceC
   *pixelX = (int) (xTile * tileSize[0] + ((unsigned int) launchX & (tileSize[0] - 1)));
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_tile_column")
 
 int twk_launch_width(int width, int tileSizeX, int deviceCount, int* launchWidth)
+try
 {
   if (!launchWidth || deviceCount < 1 || tileSizeX < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_launch_width: bad arguments");
   const int w    = (width + deviceCount - 1) / deviceCount;
@@ -318,8 +371,10 @@ int twk_launch_width(int width, int tileSizeX, int deviceCount, int* launchWidth
   *launchWidth = (w + mask) & ~mask;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_launch_width")
 
 int twk_parse_tokens(const char* text, char* out, size_t capacity, int* numTokens)
+try
 {
   if (!text || !out || !numTokens) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_parse_tokens: NULL argument");
   DescriptionParser parser;
@@ -338,5 +393,6 @@ int twk_parse_tokens(const char* text, char* out, size_t capacity, int* numToken
   *numTokens = count;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_parse_tokens")
 
 } // extern "C"

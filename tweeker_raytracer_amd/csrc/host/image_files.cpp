@@ -208,6 +208,10 @@ bool decodePng(const std::vector<unsigned char>& file, int& width, int& height, 
   if (colour == 3 && palette.size() < 3) { error = "PNG: palette missing"; return false; }
 
   const size_t rowBytes = ((size_t) width * channels * depth + 7) / 8;
+  // IHDR is untrusted: deflate expands at most ~1032:1, so a picture whose raw size exceeds that bound of its IDAT
+  // bytes cannot be valid — refuse before allocating width x height from the header alone
+  if ((rowBytes + 1) * (size_t) height > idat.size() * 1032 + 65536 || (size_t) width * (size_t) height > ((size_t) 1 << 31))
+  { error = "PNG: image dimensions do not fit the compressed data"; return false; }
   std::vector<unsigned char> raw((rowBytes + 1) * (size_t) height);
   uLongf rawSize = (uLongf) raw.size();
   if (uncompress(raw.data(), &rawSize, idat.data(), (uLong) idat.size()) != Z_OK || rawSize != raw.size()) { error = "PNG: inflate failed"; return false; }
@@ -271,6 +275,9 @@ bool decodeHdr(const std::vector<unsigned char>& file, int& width, int& height, 
   line(s);
   if (sscanf(s.c_str(), "-Y %d +X %d", &height, &width) != 2 || width <= 0 || height <= 0) { error = "HDR: only the standard orientation '-Y h +X w' is supported"; return false; }
 
+  // untrusted header: a run-length scanline of w pixels takes at least 4 + 4 * ceil(w / 127) * 2 bytes, a flat one 4 w —
+  // a picture with more rows than remaining bytes / 8 cannot be complete
+  if ((size_t) height > (file.size() - pos) / 8 + 1 || (size_t) width > ((size_t) 1 << 24)) { error = "HDR: resolution does not fit the file"; return false; }
   rgba.assign((size_t) width * height * 4, 1.0f);
   std::vector<unsigned char> scan((size_t) width * 4);
   for (int y = 0; y < height; ++y)
