@@ -2,7 +2,8 @@
 """HBM-side traffic of the traversal kernel from rocprofv3 --pmc passes (tools/pmc_collect.sh):
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of 16-B-per-lane reads
 (MI355X_MICROARCH.md §HBM), so it is doubled; WRITE_SIZE is exact for 16-B stores. Averages per dispatch of
-twk::traceKernel<false>. usage: tools/pmc_traffic.py gpurun_out/<tag> profiles/r01_trace_hbm_traffic.json"""
+twk::traceKernel<false, ...>; steps / batch depth / resolution of the profiled bench run are recorded so that bench.py
+reports the figure only for a matching run. usage: tools/pmc_traffic.py gpurun_out/<tag> profiles/r02_trace_hbm_traffic.json"""
 import csv, glob, json, os, sys
 
 root, out = sys.argv[1], sys.argv[2]
@@ -17,7 +18,8 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 per = {c: v[0] / max(1, len(v[1])) for c, v in acc.items()}
 res = {
-    "kernel": "twk::traceKernel<false, false>",
+    "kernel": "twk::traceKernel<false, false, *>",
+    "steps": int(os.environ.get("TWK_PMC_STEPS", "64")), "batch_depth": int(os.environ.get("TWK_PMC_STEPS", "64")), "resolution": [1920, 1080],
     "dispatches": len(acc["FETCH_SIZE"][1]),
     "fetch_size_kib_per_launch": per["FETCH_SIZE"],
     "write_size_kib_per_launch": per["WRITE_SIZE"],

@@ -1230,7 +1230,7 @@ try
 {
   int rc = activate(dev, "twk_stream_peak_gbps"); if (rc) return rc;
   if (!gbps || bytes < 4096 || repeats < 1) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_stream_peak_gbps: bad arguments");
-  const size_t n = bytes / sizeof(float4);
+  const size_t n = (bytes / sizeof(float4)) & ~(size_t) 1023; // whole 16 KiB pieces of the copy kernel
   float4 *a = nullptr, *b = nullptr;
   HIP_TRY(hipMalloc(&a, n * sizeof(float4)));
   if (hipMalloc(&b, n * sizeof(float4)) != hipSuccess) { (void) hipFree(a); return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "twk_stream_peak_gbps: out of memory"); }

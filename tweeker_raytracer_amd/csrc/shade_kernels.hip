@@ -328,9 +328,18 @@ __global__ void tonemapKernel(const float4* __restrict__ hdr, unsigned char* __r
   }
 }
 
-__global__ void streamCopyKernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+// Stream-copy peak (measurement only, twk_stream_peak_gbps): four 16-byte loads in flight per lane before the stores,
+// block-contiguous 4 KiB pieces.
+__global__ void __launch_bounds__(256) streamCopyKernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
-  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
+  const size_t stride = (size_t) gridDim.x * blockDim.x * 4;
+  size_t i = (size_t) blockIdx.x * blockDim.x * 4 + threadIdx.x;
+  for (; i + 3 * 256 < n; i += stride)
+  {
+    const float4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+    dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+  }
+  for (; i < n; i += 256) dst[i] = src[i]; // tail of the last piece (n is a multiple of 256 in twk_stream_peak_gbps)
 }
 
 // Divergent-gather ceiling of the chip (measurement only, twk_gather_peak): every lane walks its own pseudo-random
@@ -409,7 +418,7 @@ void launchTonemap(const float4* hdr, unsigned char* ldr, size_t numPixels, cons
 }
 void launchStreamCopy(const float4* src, float4* dst, size_t n, hipStream_t stream)
 {
-  hipLaunchKernelGGL(streamCopyKernel, dim3(2048), dim3(256), 0, stream, src, dst, n);
+  hipLaunchKernelGGL(streamCopyKernel, dim3(4096), dim3(256), 0, stream, src, dst, n);
 }
 
 } // namespace twk
