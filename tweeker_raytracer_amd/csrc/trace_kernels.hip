@@ -263,14 +263,14 @@ traceKernel(LaunchParams p, int depth)
 
       // one leaf / instance-entry / instance-exit step per lane; lanes that left the node loop early are still
       // at an inner node and must NOT take this path (their `node` is not a leaf reference)
+      unsigned int pop = 0u; // lane flag kept in a vector register, like `state`
+      // Triangle range this lane tests in this round: the slots of a bottom-level leaf (object space, inside an
+      // instance) or the world-space slots of a flattened instance at the top level. ONE triangle phase serves both:
+      // `woop` and `ray.o` always belong to the space the lane is in.
+      int triFirst = 0, triLast = -1;
       if ((state & ST_HAS_RAY) && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
       {
-        unsigned int pop = 0u; // lane flag kept in a vector register, like `state`
         TWK_WAVE_STEP(leafWaveSteps)
-        // Triangle range this lane tests in this round: the slots of a bottom-level leaf (object space, inside an
-        // instance) or the world-space slots of a flattened instance at the top level. ONE triangle loop serves both:
-        // `woop` and `ray.o` always belong to the space the lane is in.
-        int triFirst = 0, triLast = -1;
         if (TWO_LEVEL && node == TWK_BVH_SENTINEL)
         {
           // leaving an instance: the world-space Woop constants saved at entry come back from the stack
@@ -321,29 +321,39 @@ traceKernel(LaunchParams p, int depth)
           }
         }
 
-        for (int ts = triFirst; ts <= triLast; ++ts)
-        {
-          const float4* tri = p.triangles + 3 * (size_t) ts;
-          const float4 a = tri[0], b = tri[1], c = tri[2];
-          if (COUNT) ++triCount;
-          TWK_WAVE_STEP(triWaveSteps)
-          float t, beta, gamma;
-          const bool hit = woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma);
-          const int prim = __float_as_int(a.w);
-          const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b.w); // world-space slots carry their instance
-          const bool closer = hit & ((t < res.t) |
-                                     ((t == res.t) & (res.instance >= 0) &
-                                      ((triInstance < res.instance) | ((triInstance == res.instance) & (prim < res.primitive)))));
-          res.t = closer ? t : res.t; res.beta = closer ? beta : res.beta; res.gamma = closer ? gamma : res.gamma;
-          res.instance = closer ? triInstance : res.instance; res.primitive = closer ? prim : res.primitive; res.triangleSlot = closer ? ts : res.triangleSlot;
-          if (closer & ((state & ST_ANY_HIT) != 0u)) { pop = 0u; state = (state & ~ST_HAS_RAY) | ST_DONE; break; }
-        }
+      }
 
-        if (pop)
-        {
-          if (sp == 0) state = (state & ~ST_HAS_RAY) | ST_DONE;
-          else { --sp; node = ldsStack[sp * stride]; }
-        }
+      // ---- triangle phase -----------------------------------------------------------------------------------------
+#define TWK_MERGE_HIT(hit_, t_, beta_, gamma_, inst_, prim_, ts_)                                                              \
+      {                                                                                                                        \
+        const bool closer = (hit_) & (((t_) < res.t) |                                                                         \
+                                      (((t_) == res.t) & (res.instance >= 0) &                                                 \
+                                       (((inst_) < res.instance) | (((inst_) == res.instance) & ((prim_) < res.primitive))))); \
+        res.t = closer ? (t_) : res.t; res.beta = closer ? (beta_) : res.beta; res.gamma = closer ? (gamma_) : res.gamma;      \
+        res.instance = closer ? (inst_) : res.instance; res.primitive = closer ? (prim_) : res.primitive;                      \
+        res.triangleSlot = closer ? (ts_) : res.triangleSlot;                                                                  \
+        if (closer & ((state & ST_ANY_HIT) != 0u)) { pop = 0u; state = (state & ~ST_HAS_RAY) | ST_DONE; triLast = -1; }        \
+      }
+      // (Handing a leaf's second triangle to an idle lane through the lane crossbar — 17 ds_bpermute + an LDS pairing table —
+      // was built and measured: triangle-test lane occupancy 0.33 -> 0.59, kernel time +23 %. Not kept.)
+      for (int ts = triFirst; ts <= triLast; ++ts)
+      {
+        const float4* tri = p.triangles + 3 * (size_t) ts;
+        const float4 a = tri[0], b = tri[1], c = tri[2];
+        if (COUNT) ++triCount;
+        TWK_WAVE_STEP(triWaveSteps)
+        float t, beta, gamma;
+        const bool hit = woopIntersect(woop, ray.o, v3(a), v3(b), v3(c), tmin, t, beta, gamma);
+        const int prim = __float_as_int(a.w);
+        const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b.w); // world-space slots carry their instance
+        TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts)
+      }
+#undef TWK_MERGE_HIT
+
+      if (pop)
+      {
+        if (sp == 0) state = (state & ~ST_HAS_RAY) | ST_DONE;
+        else { --sp; node = ldsStack[sp * stride]; }
       }
 
       // write the result of rays that completed in this round
