@@ -347,6 +347,30 @@ def main():
             "sample_bit_identical_to_gpu": bool(np.array_equal(cpu_img.view(np.uint32), gpu_img.view(np.uint32))),
         }
 
+        # ---- the same BVH on one host core: the device-built tree walked by the host walker of the test tooling on the
+        # rays real paths trace (closest-hit and shadow rays of 4,096 pixels of iteration 0, taken from the oracle)
+        acc = dev.readAcceleration()
+        rng = np.random.default_rng(11)
+        pix = rng.integers(0, width * height, 4096)
+        path_rays = np.concatenate([ref.debugPath(0, int(i % width), int(i // width)) for i in pix])
+        closest, shadow = path_rays[path_rays[:, 8] == 0][:, :8], path_rays[path_rays[:, 8] != 0][:, :8]
+        tw = time.perf_counter()
+        repeats = 0
+        counts = {"nodesVisited": 0, "trianglesTested": 0}
+        while time.perf_counter() - tw < 2.0:
+            for rays_, any_hit in ((closest, False), (shadow, True)):
+                if len(rays_):
+                    _, _, c = orc.walk_same_bvh(acc, rays_, anyHit=any_hit)
+                    counts = {k: counts[k] + c[k] for k in counts}
+            repeats += 1
+        walk_s = time.perf_counter() - tw
+        n_walk = (len(closest) + len(shadow)) * repeats
+        result["cpu_baseline"]["same_bvh_traversal"] = {
+            "value": n_walk / walk_s / 1.0e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/same_bvh_walk.cpp on the device-built tree: {len(closest)} closest-hit + {len(shadow)} shadow rays of 4096 pixels' paths, {repeats} repeats in {walk_s:.1f} s",
+            "nodes_per_ray": counts["nodesVisited"] / max(1, n_walk), "triangles_per_ray": counts["trianglesTested"] / max(1, n_walk),
+        }
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     dev.close()

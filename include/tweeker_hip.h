@@ -315,6 +315,21 @@ int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma /*3 per px*/, int
  * Geometric query: cutout opacity is not applied here. */
 int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids);
 
+/* Read-back of the acceleration structure twk_build produced, for the same-BVH host walker of the test tooling
+ * (oracle/same_bvh_walk.cpp: visit counts and a one-core traversal rate on exactly the tree the kernels walk).
+ * Two-call protocol: with NULL buffers only `info` is filled. wideNodes: numNodes x 128 B (eight float4: lo_k.xyz, hi_k.xyz
+ * of the four children, their references in the .w of the first four; reference >= 0 inner node, < 0 leaf with
+ * payload ~ref = instance index, or first slot | (count - 1) << 28 [| 0x40000000 for world-space slots]);
+ * triangles: numTriangleSlots x 48 B (three float4: vertex, .w = primitive index / instance index / 0);
+ * instances: numInstances x 128 B (world-to-object 3x4, BVH root, ..., see csrc/device_types.h DevInstance). */
+typedef struct TwkAccelerationInfo
+{
+  int      root;      /* node index traversal starts at */
+  int      twoLevel;  /* 0: every instance is flattened, no instance reference occurs */
+  uint64_t numNodes, numTriangleSlots, numInstances;
+} TwkAccelerationInfo;
+int twk_debug_read_acceleration(TwkDevice dev, TwkAccelerationInfo* info, void* wideNodes, void* triangles, void* instances);
+
 /* Unit taps of the device math used by the shaders (bit-exact parity with the oracle):
  * op 0 sin, 1 cos, 2 exp, 3 atan2(x[i], y[i]), 4 acos, 5 atan, 6 sqrt, 7 1/x, 8 log, 9 pow(x[i], y[i]). */
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n);

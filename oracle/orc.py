@@ -196,6 +196,22 @@ class Oracle:
         return tbg, ids
 
 
+def walk_same_bvh(acceleration, rays, anyHit=False):
+    """Same-BVH host walker (oracle/same_bvh_walk.cpp): `acceleration` = Device.readAcceleration(); rays [n, 8].
+    Returns (t/beta/gamma [n, 3], ids [n, 2], counts dict) — single-threaded."""
+    lib = _load(ORACLE_PATH)
+    info, nodes, tris, inst = acceleration
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+    n = rays.shape[0]
+    tbg = np.zeros((n, 3), np.float32)
+    ids = np.zeros((n, 2), np.int32)
+    counts = (C.c_uint64 * 4)()
+    rc = lib.orc_walk_same_bvh(_f(nodes), int(info["root"]), _f(tris), _f(inst), _f(rays), C.c_uint64(n), int(bool(anyHit)),
+                               _f(tbg), ids.ctypes.data_as(_ip), counts)
+    assert rc == 0
+    return tbg, ids, {"nodesVisited": counts[0], "trianglesTested": counts[1], "instancesEntered": counts[2], "deepestStack": counts[3]}
+
+
 def oracle_math(op, x, y=None, libm=False):
     lib = _load(ORACLE_LIBM_PATH if libm else ORACLE_PATH)
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)

@@ -298,3 +298,45 @@ def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
         dev.render(0)                # recorded; reported by the call that runs the pass
         dev.synchronizeStream()
     dev.close()
+
+
+@pytest.mark.parametrize("scene_file,two_level", [("scene_rtigo3_cornell_box.txt", False), ("scene_rtigo3_instances.txt", True)])
+def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, scene_file, two_level):
+    """The single-threaded host walker of the test tooling (oracle/same_bvh_walk.cpp) walks the tree the DEVICE built
+    (twk_debug_read_acceleration) with the persistent kernel's per-ray algorithm: its hit records equal the device's
+    bit for bit and its visit counts equal the counting kernel's (counts from the CPU running the same
+    BVH on the same rays). Primary rays only: no lights, black miss, one segment."""
+    from conftest import scene_path
+    system = "\n".join(["resolution 64 40", "tileSize 8 8", "samplesSqrt 1", "miss 0", "light 0", "pathLengths 1 1", "epsilonFactor 500",
+                        "lensShader 0", "center 0 1 0", "camera 0.75 0.5 45 3.41" if not two_level else "camera 0.75 0.55 50 14"]) + "\n"
+    app = twk.Application(system_text=system, scene_text=open(scene_path(scene_file)).read())
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    acc = dev.readAcceleration()
+    assert bool(acc[0]["twoLevel"]) == two_level
+    dev.debugCapture(True)
+    dev.statsEnable(True)
+    dev.statsGet(reset=True)
+    dev.render(0)
+    st = dev.statsGet(reset=True)
+    g_tbg, g_ids = dev.debugReadFirstHits()
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    w, h = 64, 40
+    rays = np.stack([ref.debugPath(0, x, y)[0][:8] for y in range(h) for x in range(w)])
+    assert st["radianceRays"] == w * h and st["shadowRays"] == 0
+    c_tbg, c_ids, counts = orc.walk_same_bvh(acc, rays)
+    assert np.array_equal(c_ids, g_ids)
+    hit = c_ids[:, 0] >= 0
+    assert 0.3 < hit.mean() <= 1.0
+    assert np.array_equal(_bits(c_tbg[hit]), _bits(g_tbg[hit]))
+    # v_rcp_f32 (device) vs 1.0f / d (host) in the culling test may move a borderline box decision: a few visits in a million
+    assert abs(int(counts["nodesVisited"]) - int(st["nodesVisited"])) <= max(2, st["nodesVisited"] // 2000), (counts, st["nodesVisited"])
+    assert abs(int(counts["trianglesTested"]) - int(st["trianglesTested"])) <= max(2, st["trianglesTested"] // 2000), (counts, st["trianglesTested"])
+    assert int(counts["instancesEntered"]) == int(st["instancesEntered"]) or abs(int(counts["instancesEntered"]) - int(st["instancesEntered"])) <= 2
+    if two_level:
+        assert counts["instancesEntered"] > 0
+    # and against brute force through the oracle
+    o_tbg, o_ids = ref.traceRays(rays)
+    assert np.array_equal(o_ids, c_ids) and np.array_equal(_bits(o_tbg[hit]), _bits(c_tbg[hit]))
+    dev.close()

@@ -1337,6 +1337,22 @@ try
 }
 TWK_CATCH("twk_trace_rays")
 
+int twk_debug_read_acceleration(TwkDevice dev, TwkAccelerationInfo* info, void* wideNodes, void* triangles, void* instances)
+try
+{
+  int rc = activate(dev, "twk_debug_read_acceleration"); if (rc) return rc;
+  if (!info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_read_acceleration: NULL info");
+  if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_read_acceleration: twk_build has not been called");
+  info->root = dev->tlasRoot; info->twoLevel = dev->twoLevel ? 1 : 0;
+  info->numNodes = dev->totalNodes; info->numTriangleSlots = dev->totalTriangles; info->numInstances = dev->instances.size();
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, dev->d_wideNodes, sizeof(BvhNode) * 2 * dev->totalNodes, hipMemcpyDeviceToHost));
+  if (triangles) HIP_TRY(hipMemcpy(triangles, dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles, hipMemcpyDeviceToHost));
+  if (instances) HIP_TRY(hipMemcpy(instances, dev->d_instances, sizeof(DevInstance) * dev->instances.size(), hipMemcpyDeviceToHost));
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_debug_read_acceleration")
+
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n)
 try
 {

@@ -223,6 +223,17 @@ class Device:
         L.check(L.lib.twk_gather_peak(self._h, C.c_size_t(int(table_bytes)), C.byref(g)))
         return g.value
 
+    def readAcceleration(self):
+        """(info dict, wide nodes float32 [n, 32], triangle slots float32 [m, 12], instance records float32 [k, 32]) of the built scene."""
+        info = L.AccelerationInfo()
+        L.check(L.lib.twk_debug_read_acceleration(self._h, C.byref(info), None, None, None))
+        nodes = np.zeros((info.numNodes, 32), np.float32)
+        tris = np.zeros((info.numTriangleSlots, 12), np.float32)
+        inst = np.zeros((info.numInstances, 32), np.float32)
+        L.check(L.lib.twk_debug_read_acceleration(self._h, C.byref(info), nodes.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p),
+                                                  inst.ctypes.data_as(C.c_void_p)))
+        return {name: getattr(info, name) for name, _ in L.AccelerationInfo._fields_}, nodes, tris, inst
+
     def debugCapture(self, enable=True):
         L.check(L.lib.twk_debug_capture(self._h, int(bool(enable))))
 
