@@ -16,5 +16,6 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD SQ_WAVES SQ_INSTS_VALU_TRANS_F32
 run tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-# (TA_* counters hang rocprofv3 on this pool: two runs were killed by the silence guard — do not add them back)
+# TA_* counters: two round-1 runs that added a TA pass were killed by gpurun's silence guard; see profiles/README.md
+# ("The two killed TA_* counter runs") for what is and is not known about them. They are not added back.
 find $OUT -name "*.csv" | head -20
