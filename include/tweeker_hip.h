@@ -267,6 +267,14 @@ int twk_get_output_device_pointer(TwkDevice dev, void** dptr, size_t* bytes);
  * torch tensor used as RCCL send buffer). Pass NULL to return to the internal buffer. */
 int twk_set_output_device_pointer(TwkDevice dev, void* dptr, size_t bytes);
 
+/* The reference's two other multi-GPU buffer strategies (≙ DeviceMultiGPUZeroCopy.cpp:106-118: one pinned host buffer
+ * mapped into every device; DeviceMultiGPUPeerAccess.cpp:110-158: one buffer on the first device, written by its peers):
+ * every device accumulates straight into ONE shared W x H RGBA32F frame at the pixel its launch index maps to
+ * (raygeneration.cu:175-183,229), no packed tile buffers, no compositor. `frame` must be addressable from this device
+ * (hipHostMalloc(..., hipHostMallocPortable | hipHostMallocMapped), or device memory with peer access enabled);
+ * devices write disjoint pixels. NULL returns to the internal packed buffer. twk_read_output then returns the frame. */
+int twk_set_shared_frame(TwkDevice dev, void* frame, size_t bytes);
+
 /* ≙ DeviceMultiGPULocalCopy::compositor + compositor.cu:38-64, for all source devices in one kernel:
  * `tiles` is the gathered [deviceCount][H][launchWidth] RGBA32F block (device memory, rank order),
  * `output` the full W×H RGBA32F image (device memory). Runs on this handle's stream. */

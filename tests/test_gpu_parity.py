@@ -209,6 +209,45 @@ def test_tiled_equals_single_device(twk):
         assert np.array_equal(_bits(out), _bits(full)), f"tiled N={n} differs from single device"
 
 
+def test_shared_frame_strategies_equal_single_device(twk):
+    """twk_set_shared_frame (≙ the ZeroCopy / PeerAccess strategies): N handles accumulate straight into ONE W x H frame
+    at the pixels their launch indices map to; the frame equals the single-device image bit for bit. The frame here is
+    device memory of the one GPU all handles share."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    res = (200, 120)  # not a multiple of 8 * N: the last tile column is partly outside the image
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", res)
+    single = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(single)
+    for it in range(3):
+        single.render(it)
+    full = single.getOutputBufferHost()
+    single.close()
+    for n in (2, 3):
+        nbytes = res[0] * res[1] * 16
+        frame = C.c_void_p()
+        assert hip.hipMalloc(C.byref(frame), C.c_size_t(nbytes)) == 0
+        assert hip.hipMemset(frame, 0, C.c_size_t(nbytes)) == 0
+        handles = []
+        for i in range(n):
+            d = twk.Device(ordinal=0, index=i, count=n, miss=app.info.miss)
+            app.initDevice(d, distribution=1)
+            d.setSharedFrame(frame.value, nbytes)
+            handles.append(d)
+        for it in range(3):
+            for d in handles:
+                d.render(it)
+        for d in handles:
+            d.synchronizeStream()
+        host = np.empty((res[1], res[0], 4), np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), frame, C.c_size_t(nbytes), 2) == 0  # hipMemcpyDeviceToHost
+        assert np.array_equal(_bits(host), _bits(full)), f"shared frame of {n} handles differs from the single-device image"
+        assert np.array_equal(_bits(handles[0].getOutputBufferHost()), _bits(full))
+        for d in handles:
+            d.close()
+        assert hip.hipFree(frame) == 0
+
+
 def test_error_paths(twk):
     """Error behaviour of the C ABI: invalid calls return codes + message, never crash."""
     dev = twk.Device(ordinal=0)

@@ -96,9 +96,13 @@ def test_command_line_benchmark_and_screenshot(twk, orc, tmp_path):
         ref.render(i)
     expect = orc.oracle_tonemap(ref.getOutputBufferHost(), TM)[::-1]  # the file stores the top row first
     assert png.shape == (64, 96, 3) and np.array_equal(png, expect)
-    # strategy 1: three handles share this GPU, tiles → peer copies → one compositor launch → same picture
-    _, png3 = _run_cli(tmp_path, 1, env={"TWK_CLI_VIRTUAL_DEVICES": "3"})
-    assert np.array_equal(png3, expect), f"{(png3 != expect).any(-1).sum()} of {png3.shape[0] * png3.shape[1]} pixels differ, columns {np.unique(np.nonzero((png3 != expect).any(-1))[1])[:40]}"
+    # The reference's three multi-GPU buffer strategies, three handles sharing this GPU: 3 = local copy (packed tile
+    # buffers → peer copies → one compositor launch), 1 = zero copy (every handle accumulates into ONE pinned host frame,
+    # DeviceMultiGPUZeroCopy.cpp:106-118), 2 = peer access (ONE frame in the first device's memory,
+    # DeviceMultiGPUPeerAccess.cpp:110-158) → the same picture each time
+    for strategy in (3, 1, 2):
+        _, png3 = _run_cli(tmp_path, strategy, env={"TWK_CLI_VIRTUAL_DEVICES": "3"})
+        assert np.array_equal(png3, expect), f"strategy {strategy}: {(png3 != expect).any(-1).sum()} of {png3.shape[0] * png3.shape[1]} pixels differ, columns {np.unique(np.nonzero((png3 != expect).any(-1))[1])[:40]}"
 
 
 def test_command_line_environment_map_from_file(twk, orc, tmp_path):

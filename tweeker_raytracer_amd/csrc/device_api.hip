@@ -113,6 +113,7 @@ struct TwkDevice_t
   void* d_streamBlock = nullptr; // one allocation carved into the SoA streams
   float4* d_outputInternal = nullptr;
   float4* d_outputExternal = nullptr; size_t outputExternalBytes = 0;
+  bool outputFrame = false; // the external buffer is a shared full frame (twk_set_shared_frame)
   unsigned int* d_counters = nullptr;
   unsigned long long* d_stats = nullptr;
   int* d_spill = nullptr; size_t spillLanes = 0;
@@ -242,6 +243,7 @@ static void refreshParams(TwkDevice dev)
   p.batchCount = 1;
   p.numPaths = p.numPixels;
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
+  p.outputFrame = (dev->d_outputExternal && dev->outputFrame) ? 1 : 0;
   p.counters = dev->d_counters;
   p.stats = dev->statsEnabled ? dev->d_stats : nullptr;
   p.shaderVariant = dev->shaderVariant;
@@ -611,9 +613,10 @@ try
     dev->launchWidth = (width + mask) & ~mask;
   }
   else dev->launchWidth = s->resolution[0];
-  if (dev->d_outputExternal && dev->outputExternalBytes < (size_t) dev->launchWidth * s->resolution[1] * sizeof(float4))
+  const size_t needBytes = (size_t) (dev->outputFrame ? s->resolution[0] : dev->launchWidth) * s->resolution[1] * sizeof(float4);
+  if (dev->d_outputExternal && dev->outputExternalBytes < needBytes)
   {
-    dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; // too small for the new state: fall back to the internal buffer
+    dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; dev->outputFrame = false; // too small for the new state: fall back to the internal buffer
   }
   return TWK_SUCCESS;
 }
@@ -1054,8 +1057,8 @@ try
 {
   int rc = activate(dev, "twk_read_output"); if (rc) return rc;
   if (!rgbaHost) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: NULL buffer");
-  const size_t n = (size_t) dev->launchWidth * dev->state.resolution[1];
-  if (numFloats != n * 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: buffer must hold launchWidth*height*4 floats");
+  const size_t n = (size_t) ((dev->d_outputExternal && dev->outputFrame) ? dev->state.resolution[0] : dev->launchWidth) * dev->state.resolution[1];
+  if (numFloats != n * 4) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_read_output: buffer must hold launchWidth*height*4 floats (width*height*4 with a shared frame)");
   const float4* src = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   if (!src) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_read_output: nothing has been rendered");
   HIP_TRY(hipStreamSynchronize(dev->stream));
@@ -1119,13 +1122,26 @@ try
 {
   int rc = activate(dev, "twk_set_output_device_pointer"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  if (dptr == nullptr) { dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; return TWK_SUCCESS; }
+  if (dptr == nullptr) { dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; dev->outputFrame = false; return TWK_SUCCESS; }
   if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_set_output_device_pointer: twk_set_state first");
   if (bytes < (size_t) dev->launchWidth * dev->state.resolution[1] * sizeof(float4)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_output_device_pointer: buffer smaller than launchWidth*height*16 bytes");
-  dev->d_outputExternal = static_cast<float4*>(dptr); dev->outputExternalBytes = bytes;
+  dev->d_outputExternal = static_cast<float4*>(dptr); dev->outputExternalBytes = bytes; dev->outputFrame = false;
   return TWK_SUCCESS;
 }
 TWK_CATCH("twk_set_output_device_pointer")
+
+int twk_set_shared_frame(TwkDevice dev, void* frame, size_t bytes)
+try
+{
+  int rc = activate(dev, "twk_set_shared_frame"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (frame == nullptr) { dev->d_outputExternal = nullptr; dev->outputExternalBytes = 0; dev->outputFrame = false; return TWK_SUCCESS; }
+  if (!dev->stateSet) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_set_shared_frame: twk_set_state first");
+  if (bytes < (size_t) dev->state.resolution[0] * dev->state.resolution[1] * sizeof(float4)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_set_shared_frame: buffer smaller than width*height*16 bytes");
+  dev->d_outputExternal = static_cast<float4*>(frame); dev->outputExternalBytes = bytes; dev->outputFrame = true;
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_set_shared_frame")
 
 int twk_compositor(TwkDevice dev, const void* tiles, void* output)
 try

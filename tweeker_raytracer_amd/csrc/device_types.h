@@ -180,6 +180,7 @@ struct LaunchParams
   float4* aovAlbedo;      // their running means per launch index (raygeneration.cu:239-262)
   float4* aovNormal;
   int     shaderVariant;  // TWK_SHADERS_RTIGO3 / TWK_SHADERS_OPTIX7GUI (include/tweeker_hip.h)
+  int     outputFrame;    // 1: `output` is a shared full W x H frame addressed by absolute pixel (ZeroCopy / PeerAccess strategies), 0: this device's packed launchWidth x H buffer
   float4* output;         // running mean, RGBA32F
   unsigned int* counters; // see CounterSlot
   unsigned long long* stats; // TwkLaunchStats as 7 u64, or nullptr

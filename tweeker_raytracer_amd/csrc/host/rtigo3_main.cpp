@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
@@ -142,6 +143,35 @@ int main(int argc, char* argv[])
     for (int i = 0; i < count; ++i) TWK_OK(twk_init_texture(devices[(size_t) i], picture.slot, rgba.data(), w, h));
   }
   for (int i = 0; i < count; ++i) TWK_OK(twk_app_init_device(app, devices[(size_t) i]));
+
+  // Buffer strategy (Raytracer.cpp:125-176 picks the Device flavour): 1 = zero copy — one pinned host frame mapped into
+  // every device (DeviceMultiGPUZeroCopy.cpp:106-118); 2 = peer access — one frame on the first device, written by its
+  // peers (DeviceMultiGPUPeerAccess.cpp:110-158); 3 = local copy — packed tile buffers + compositor.
+  void* sharedFrame = nullptr;
+  const size_t frameBytes = (size_t) info.resolution[0] * info.resolution[1] * 16;
+  if (count > 1 && info.strategy == 1)
+  {
+    HIP_OK(hipHostMalloc(&sharedFrame, frameBytes, hipHostMallocPortable | hipHostMallocMapped));
+    memset(sharedFrame, 0, frameBytes);
+  }
+  else if (count > 1 && info.strategy == 2)
+  {
+    HIP_OK(hipSetDevice(ordinals[0]));
+    HIP_OK(hipMalloc(&sharedFrame, frameBytes));
+    HIP_OK(hipMemset(sharedFrame, 0, frameBytes));
+    for (int i = 1; i < count; ++i)
+    {
+      if (ordinals[(size_t) i] == ordinals[0]) continue;
+      int canAccess = 0;
+      HIP_OK(hipDeviceCanAccessPeer(&canAccess, ordinals[(size_t) i], ordinals[0]));
+      if (!canAccess) { std::cerr << "ERROR: device " << ordinals[(size_t) i] << " cannot access the frame on device " << ordinals[0] << " (strategy 2 needs one peer-to-peer island)\n"; return 1; }
+      HIP_OK(hipSetDevice(ordinals[(size_t) i]));
+      const hipError_t e = hipDeviceEnablePeerAccess(ordinals[0], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { std::cerr << "ERROR: hipDeviceEnablePeerAccess: " << hipGetErrorString(e) << std::endl; return 1; }
+      (void) hipGetLastError();
+    }
+  }
+  if (sharedFrame) for (int i = 0; i < count; ++i) TWK_OK(twk_set_shared_frame(devices[(size_t) i], sharedFrame, frameBytes));
   std::cerr << "INFO: " << count << " device(s), " << info.resolution[0] << " x " << info.resolution[1] << ", "
             << info.samplesSqrt * info.samplesSqrt << " spp, " << info.numInstances << " instances" << std::endl;
 
@@ -174,6 +204,10 @@ int main(int argc, char* argv[])
   {
     TWK_OK(twk_tonemap(devices[0], &tonemapper, nullptr, numPixels, rgb8.data()));
   }
+  else if (sharedFrame)
+  {
+    TWK_OK(twk_tonemap(devices[0], &tonemapper, sharedFrame, numPixels, rgb8.data())); // every device wrote its pixels straight into the frame
+  }
   else
   {
     int launchWidth = 0;
@@ -202,6 +236,7 @@ int main(int argc, char* argv[])
   std::cout << path << std::endl;
 
   for (int i = 0; i < count; ++i) TWK_OK(twk_device_destroy(devices[(size_t) i]));
+  if (sharedFrame) { if (info.strategy == 1) (void) hipHostFree(sharedFrame); else (void) hipFree(sharedFrame); }
   TWK_OK(twk_app_destroy(app));
   return 0;
 }

@@ -211,7 +211,18 @@ __global__ void __launch_bounds__(256) accumulateKernel(LaunchParams p)
   const unsigned int index = blockIdx.x * blockDim.x + threadIdx.x;
   if (index >= (unsigned int) p.numPixels) return;
   const bool aov = (p.aovAlbedo != nullptr);
-  float4 dst = p.output[index];
+  // Where this launch index accumulates: its slot of the packed tile buffer (single device, LocalCopy), or — shared
+  // frame of the ZeroCopy / PeerAccess strategies — the pixel it maps to, as __raygen__path_tracer addresses
+  // sysData.outputBuffer (raygeneration.cu:175-183,229): index = y * W + distribute(launch index)
+  size_t outIndex = index;
+  if (p.outputFrame)
+  {
+    const unsigned int lx = index % (unsigned int) p.launchWidth, ly = index / (unsigned int) p.launchWidth;
+    const unsigned int column = (p.distribution && 1 < p.deviceCount) ? distribute(p, lx, ly) : lx;
+    if (column >= (unsigned int) p.resolution[0]) return;
+    outIndex = (size_t) ly * (unsigned int) p.resolution[0] + column;
+  }
+  float4 dst = p.output[outIndex];
   float4 dstAlbedo = aov ? p.aovAlbedo[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float4 dstNormal = aov ? p.aovNormal[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   bool touched = false;
@@ -246,7 +257,7 @@ __global__ void __launch_bounds__(256) accumulateKernel(LaunchParams p)
   }
   if (touched)
   {
-    p.output[index] = dst;
+    p.output[outIndex] = dst;
     if (aov) { p.aovAlbedo[index] = dstAlbedo; p.aovNormal[index] = dstNormal; }
   }
 }

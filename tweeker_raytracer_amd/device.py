@@ -105,6 +105,11 @@ class Device:
         L.check(L.lib.twk_add_instance(self._h, int(idGeometry), t, int(idMaterial), int(idLight), C.byref(iid)))
         return iid.value
 
+    def setSharedFrame(self, dptr, nbytes):
+        """Accumulate into a shared full W x H frame (ZeroCopy / PeerAccess strategies); 0 returns to the packed buffer."""
+        L.check(L.lib.twk_set_shared_frame(self._h, C.c_void_p(int(dptr)), C.c_size_t(int(nbytes))))
+        self._sharedFrame = bool(dptr)
+
     def setShaderVariant(self, variant):
         """0 = rtigo3 (a light's back face reflects through its BSDF), 1 = Optix7Gui (any light hit ends the path)."""
         L.check(L.lib.twk_set_shader_variant(self._h, int(variant)))
@@ -160,7 +165,7 @@ class Device:
 
     def getOutputBufferHost(self):
         """RGBA32F running mean, shape [height, launchWidth, 4] (launchWidth == width unless tiled)."""
-        h, w = self.state.resolution[1], self.launchWidth
+        h, w = self.state.resolution[1], (self.state.resolution[0] if getattr(self, "_sharedFrame", False) else self.launchWidth)
         out = np.empty((h, w, 4), dtype=np.float32)
         L.check(L.lib.twk_read_output(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(out.size)))
         return out
