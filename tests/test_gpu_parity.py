@@ -318,7 +318,7 @@ def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
     even for one iteration reports out-of-memory instead of crashing."""
     app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (96, 54))
     imgs = []
-    for budget in (None, "6"):  # 96*54 px * 344 B = 1.7 MiB per iteration: 16 iterations need 27 MiB, 3 fit in 6 MiB
+    for budget in (None, "6"):  # 96*54 px * 280 B = 1.4 MiB per iteration: 16 iterations need 22 MiB, 4 fit in 6 MiB
         if budget is None:
             monkeypatch.delenv("TWK_STREAM_BUDGET_MB", raising=False)
         else:

@@ -419,7 +419,7 @@ hipError_t BvhBuilder::buildSahTopology(hipStream_t stream, int count)
   {
     const int next = cur ^ 1;
     const int forceMiddle = (level >= 96) ? 1 : 0; // a degenerate input that SAH keeps peeling one primitive off: halve positions from here on
-    hipLaunchKernelGGL(sahClearKernel, dim3(std::min(4096, (numActive * 344 + 255) / 256)), dim3(256), 0, stream, numActive, m_sahCb, m_sahBins, m_sahFill);
+    hipLaunchKernelGGL(sahClearKernel, dim3(std::min(4096, (numActive * (6 + 3 * SAH_BINS * SAH_BIN_WORDS + 2) + 255) / 256)), dim3(256), 0, stream, numActive, m_sahCb, m_sahBins, m_sahFill);
     hipLaunchKernelGGL(sahBoundsKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb);
     hipLaunchKernelGGL(sahBinKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb, m_sahBins);
     hipLaunchKernelGGL(sahSelectKernel, dim3((numActive + 63) / 64), dim3(64), 0, stream, numActive, active[cur], m_sahBins, forceMiddle, split, nodeCounter,

@@ -83,7 +83,7 @@ template<bool COUNT, bool CUTOUT, bool TWO_LEVEL>
 #ifndef TWK_TRACE_WAVES
 #define TWK_TRACE_WAVES 6
 #endif
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // waves/SIMD; the 24-KiB LDS stacks admit 6 blocks per CU
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // waves/SIMD; 21 KiB of LDS stacks + 4.5 KiB top-of-tree cache per block admit 6 blocks per CU
 traceKernel(LaunchParams p, int depth)
 {
   __shared__ int stackStorage[(TWK_TRACE_STACK_LDS + 1) * TWK_TRACE_BLOCK]; // + 1 dummy row, see the node step
