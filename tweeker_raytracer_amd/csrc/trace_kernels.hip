@@ -207,6 +207,9 @@ traceKernel(LaunchParams p, int depth)
       {
         // one WIDE node = the four grandchildren of binary node `node`: two levels per round of loads
         float4 l0, u0, l1, u1, l2, u2, l3, u3;
+        // hipcc merges the two branches into ONE set of flat_load instructions on a selected generic pointer, and that is the
+        // faster form: forcing eight ds_read for the cached lanes and eight global_load for the others (empty asm pins in
+        // both branches) serialises two waits per step for a wave whose lanes are on both sides — 0.794 -> 0.878 ms/step.
         if (node & TWK_NODE_CACHED)
         {
           const float4* w = topCache + (node & 0xff) * TWK_TOP_STRIDE; // the top of the tree, from LDS
