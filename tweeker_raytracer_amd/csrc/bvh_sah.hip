@@ -114,26 +114,54 @@ __global__ void sahBoundsKernel(int count, const int* __restrict__ order, const 
   atomicMax(&w[3], sahOrdered(c.x)); atomicMax(&w[4], sahOrdered(c.y)); atomicMax(&w[5], sahOrdered(c.z));
 }
 
-__global__ void sahBinKernel(int count, const int* __restrict__ order, const int* __restrict__ slotOf,
+__global__ void __launch_bounds__(256) sahBinKernel(int count, const int* __restrict__ order, const int* __restrict__ slotOf,
                              const float4* __restrict__ primLo, const float4* __restrict__ primHi,
                              const unsigned int* __restrict__ cb, unsigned int* __restrict__ bins)
 {
+  // A block whose 256 positions all lie in ONE node (every block of the top levels) bins into LDS first and sends one
+  // atomic per touched word: the top levels would otherwise send every primitive's 21 atomics to the same 336 words.
+  __shared__ unsigned int local[3 * SAH_BINS * SAH_BIN_WORDS];
+  __shared__ int uniform;
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pos >= count) return;
-  const int k = slotOf[pos];
-  if (k < 0) return;
-  const int prim = order[pos];
-  const float4 lo = primLo[prim], hi = primHi[prim];
-  const V3 c = sahCentroid(lo, hi);
-  const unsigned int* w = cb + 6 * (size_t) k;
-  const float cc[3] = {c.x, c.y, c.z};
-  for (int axis = 0; axis < 3; ++axis)
+  const int k = (pos < count) ? slotOf[pos] : -1;
+  const int kFirst = slotOf[min(blockIdx.x * blockDim.x, (unsigned int) (count - 1))];
+  if (threadIdx.x == 0) uniform = 1;
+  for (int w = threadIdx.x; w < 3 * SAH_BINS * SAH_BIN_WORDS; w += blockDim.x)
   {
-    const int b = sahBin(cc[axis], sahFromOrdered(w[axis]), sahFromOrdered(w[3 + axis]));
-    unsigned int* bin = bins + ((size_t) k * 3 * SAH_BINS + (size_t) axis * SAH_BINS + b) * SAH_BIN_WORDS;
-    atomicAdd(&bin[0], 1u);
-    atomicMin(&bin[1], sahOrdered(lo.x)); atomicMin(&bin[2], sahOrdered(lo.y)); atomicMin(&bin[3], sahOrdered(lo.z));
-    atomicMax(&bin[4], sahOrdered(hi.x)); atomicMax(&bin[5], sahOrdered(hi.y)); atomicMax(&bin[6], sahOrdered(hi.z));
+    const int word = w % SAH_BIN_WORDS;
+    local[w] = (word == 0) ? 0u : ((word < 4) ? 0xffffffffu : 0u);
+  }
+  __syncthreads();
+  if (pos < count && k != kFirst) uniform = 0;
+  __syncthreads();
+  const bool useLocal = (uniform != 0) && (kFirst >= 0);
+  if (k >= 0)
+  {
+    const int prim = order[pos];
+    const float4 lo = primLo[prim], hi = primHi[prim];
+    const V3 c = sahCentroid(lo, hi);
+    const unsigned int* w = cb + 6 * (size_t) k;
+    const float cc[3] = {c.x, c.y, c.z};
+    for (int axis = 0; axis < 3; ++axis)
+    {
+      const int b = sahBin(cc[axis], sahFromOrdered(w[axis]), sahFromOrdered(w[3 + axis]));
+      unsigned int* bin = useLocal ? local + ((size_t) axis * SAH_BINS + b) * SAH_BIN_WORDS
+                                   : bins + ((size_t) k * 3 * SAH_BINS + (size_t) axis * SAH_BINS + b) * SAH_BIN_WORDS;
+      atomicAdd(&bin[0], 1u);
+      atomicMin(&bin[1], sahOrdered(lo.x)); atomicMin(&bin[2], sahOrdered(lo.y)); atomicMin(&bin[3], sahOrdered(lo.z));
+      atomicMax(&bin[4], sahOrdered(hi.x)); atomicMax(&bin[5], sahOrdered(hi.y)); atomicMax(&bin[6], sahOrdered(hi.z));
+    }
+  }
+  if (!useLocal) return; // block-uniform: no thread leaves before the barrier below
+  __syncthreads();
+  unsigned int* nodeBins = bins + (size_t) kFirst * 3 * SAH_BINS * SAH_BIN_WORDS;
+  for (int w = threadIdx.x; w < 3 * SAH_BINS * SAH_BIN_WORDS; w += blockDim.x)
+  {
+    const int word = w % SAH_BIN_WORDS;
+    const unsigned int v = local[w];
+    if (word == 0) { if (v != 0u) atomicAdd(&nodeBins[w], v); }
+    else if (word < 4) { if (v != 0xffffffffu) atomicMin(&nodeBins[w], v); }
+    else { if (v != 0u) atomicMax(&nodeBins[w], v); }
   }
 }
 
@@ -237,7 +265,21 @@ __global__ void sahPartitionKernel(int count, const int* __restrict__ order, con
     const float cc = (sp.axis == 0) ? c.x : ((sp.axis == 1) ? c.y : c.z);
     const unsigned int* w = cb + 6 * (size_t) k;
     toLeft = sahBin(cc, sahFromOrdered(w[sp.axis]), sahFromOrdered(w[3 + sp.axis])) < sp.bin;
-    const unsigned int rank = atomicAdd(&fill[2 * (size_t) k + (toLeft ? 0 : 1)], 1u);
+    // one atomic per wave and side when the whole wave sits in one node (every wave of the top levels), else one per lane
+    const unsigned long long active = __ballot(true);
+    const int k0 = __builtin_amdgcn_readfirstlane(k);
+    unsigned int rank;
+    if (__ballot(k != k0) == 0ull)
+    {
+      const unsigned long long leftMask = __ballot(toLeft), mine = toLeft ? leftMask : (active & ~leftMask);
+      const unsigned int lane = threadIdx.x & 63u;
+      const int leader = __ffsll((long long) mine) - 1;
+      unsigned int base = 0u;
+      if ((int) lane == leader) base = atomicAdd(&fill[2 * (size_t) k + (toLeft ? 0 : 1)], (unsigned int) __popcll(mine));
+      base = __shfl(base, leader);
+      rank = base + (unsigned int) __popcll(mine & ((1ull << lane) - 1ull));
+    }
+    else rank = atomicAdd(&fill[2 * (size_t) k + (toLeft ? 0 : 1)], 1u);
     target = sp.first + (toLeft ? 0 : sp.leftCount) + (int) rank;
   }
   orderNext[target] = prim;
