@@ -252,6 +252,7 @@ def main():
         gather_gbps = lane_loads * 16 / trace_s / 1.0e9
         # HBM-side bytes come from rocprofv3 --pmc passes (tools/pmc_collect.sh), which cannot run inside this process:
         # carried from the committed summary ONLY when it was taken on this very configuration, else null
+        valu_busy = None
         traffic, traffic_note = None, "no PMC summary for this configuration (tools/pmc_collect.sh + tools/pmc_traffic.py write profiles/r02_trace_hbm_traffic.json)"
         pmc_path = os.path.join(ROOT, "profiles", "r02_trace_hbm_traffic.json")
         if os.path.exists(pmc_path):
@@ -262,6 +263,7 @@ def main():
                         and pmc.get("resolution") == [width, height] and n_gpus == 1)
                 if same:
                     traffic = pmc.get("hbm_bytes_per_launch")
+                    valu_busy = pmc.get("valu_issue_utilisation")
                     traffic_note = f"carried from {os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this kernel, same steps / batch / resolution); not measured in this run"
                 else:
                     traffic_note = f"{os.path.basename(pmc_path)} was taken at steps {pmc.get('steps')}, batch {pmc.get('batch_depth')}, {pmc.get('resolution')}: not this run's launch size, so not reported"
@@ -271,6 +273,7 @@ def main():
             "algorithmic_bytes_vs_stream_peak": algo_gbps / stream_peak,
             "hbm_side_bytes_vs_stream_peak": (traffic / (trace_s / trace_launches) / 1.0e9 / stream_peak) if traffic else None,
             "lane_loads_vs_gather_ceiling": (lane_loads / trace_s / 1.0e9) / gather_peak,
+            "valu_issue_utilisation_pmc": valu_busy,  # carried with `traffic` from the same PMC passes: not a memory roofline, but what bounds the kernel now
         }
         # The scene (19 MB) lives in L2 / Infinity Cache: the algorithmic bytes are cache-level throughput and may exceed
         # what HBM could stream. The memory-side ceiling that does apply is the divergent-gather rate of the vector
