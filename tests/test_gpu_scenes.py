@@ -465,3 +465,34 @@ def test_full_size_windows(twk, orc, system, scene, windows, iters):
         assert mism == 0, f"window {(x0, y0, x1, y1)}: {mism} pixels differ, max |diff| {np.abs(g - c).max()}"
         ref.close()
     dev.close()
+
+
+@pytest.mark.parametrize("quality,top_cache", [(0, "1"), (1, "0"), (0, "0")])
+def test_build_quality_and_top_cache_do_not_change_hit_records(twk, orc, monkeypatch, quality, top_cache):
+    """twk_set_build_quality (LBVH / binned SAH) and the LDS top-of-tree cache of the trace kernel (TWK_TOP_CACHE) change
+    how rays find their hits, never which: image and first-hit records bit-identical to the oracle in every combination
+    (the default SAH + cache is what every other test runs), on a two-level and on a flattened scene."""
+    monkeypatch.setenv("TWK_TOP_CACHE", top_cache)
+    for system, scene, res in (("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (128, 72)),
+                               ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", (96, 54))):
+        app = load_app(twk, system, scene, res)
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        dev.setBuildQuality(quality)
+        app.initDevice(dev)
+        info = dev.buildInfo()
+        assert info["quality"] == quality and info["trees"] >= 1 and info["sahInnerCost"] > 0
+        ref = orc.Oracle(miss=app.info.miss)
+        ref.loadApplication(app)
+        dev.debugCapture(True)
+        ref.captureFirstHits(True)
+        dev.setLaunchBatch(1)
+        for it in range(2):
+            dev.render(it)
+            ref.render(it)
+        g_tbg, g_ids = dev.debugReadFirstHits()
+        o_tbg, o_ids = ref.readFirstHits()
+        assert np.array_equal(g_ids, o_ids)
+        hit = o_ids[:, 0] >= 0
+        assert np.array_equal(_bits(g_tbg[hit]), _bits(o_tbg[hit]))
+        assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(ref.getOutputBufferHost()))
+        dev.close()
