@@ -323,6 +323,14 @@ int twk_debug_read_first_hits(TwkDevice dev, float* tBetaGamma /*3 per px*/, int
  * Geometric query: cutout opacity is not applied here. */
 int twk_trace_rays(TwkDevice dev, const float* rays, size_t numRays, int anyHit, float* tBetaGamma, int* ids);
 
+/* The same query through the PERSISTENT traversal kernel of the hot path, as ONE bounce's launch sees it: closestRays go
+ * into the radiance ray queue, shadowRays into the shadow queue (either may be empty; 8 floats per ray as above).
+ * tBetaGammaSlot: t, beta, gamma and the bits of the hit triangle's slot per closest ray (the hit record shade reads;
+ * twk_debug_read_acceleration maps a slot to its primitive); instance: -1 on a miss; occluded: 1 / 0 per shadow ray.
+ * Overwrites the handle's path streams; not for scenes with cutout opacity. */
+int twk_debug_trace_queue(TwkDevice dev, const float* closestRays, size_t numClosest, const float* shadowRays, size_t numShadow,
+                          float* tBetaGammaSlot, int* instance, int* occluded);
+
 /* Read-back of the acceleration structure twk_build produced, for the same-BVH host walker of the test tooling
  * (oracle/same_bvh_walk.cpp: visit counts and a one-core traversal rate on exactly the tree the kernels walk).
  * Two-call protocol: with NULL buffers only `info` is filled. wideNodes: numNodes x 128 B (eight float4: lo_k.xyz, hi_k.xyz

@@ -206,3 +206,64 @@ def test_random_scenes_far_from_the_origin(twk, orc, seed, offset):
     assert np.isfinite(cpu).all() and (cpu[..., :3] > 0).mean() > 0.5
     mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
     assert mism == 0, f"{mism} of {w * h} pixels differ"
+
+
+@pytest.mark.parametrize("system,scene,lo,hi", [
+    ("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (-0.99, 0.01, -0.99), (0.99, 1.99, 0.99)),
+    ("system_rtigo3_geometry.txt", "scene_rtigo3_geometry.txt", (-7.9, -0.5, -7.9), (7.9, 3.0, 7.9)),
+    ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", (-12.0, -0.5, -12.0), (12.0, 3.5, 12.0)),
+])
+def test_persistent_kernel_against_oracle_on_adversarial_rays(twk, orc, system, scene, lo, hi):
+    """The hot traversal kernel itself (twk_debug_trace_queue: one launch of the persistent kernel, radiance and shadow
+    queue) on 400 k rays chosen to be hard: random rays, rays leaving the surfaces they start on at grazing angles with
+    the scene epsilon and with tmin 0, axis-parallel rays, rays from vertices along edges. Hit records (t, beta, gamma,
+    instance, primitive) equal the oracle's bit for bit, occlusion flags equal. (This is how round 2 would have found
+    the flat-floor box-padding miss at once instead of through one pixel of one image.)"""
+    from conftest import load_app
+    app = load_app(twk, system, scene, (32, 32))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    _, _, tris, _ = dev.readAcceleration()
+    slot_primitive = tris[:, 3].view(np.int32)
+    rng = np.random.default_rng(2026)
+    lo, hi = np.array(lo, np.float32), np.array(hi, np.float32)
+
+    def unit(v):
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    n = 100_000
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = unit(rng.normal(size=(n, 3)))
+    d[:2000, 0] = 0.0
+    d[2000:4000, 1] = 0.0
+    d[4000:5000, 1:] = 0.0  # along +-x
+    d[:5000] = unit(d[:5000] + 1e-30)
+    base = np.concatenate([o, np.full((n, 1), 5e-5, np.float32), d, np.full((n, 1), 1e27, np.float32)], 1)
+    o_tbg, o_ids = ref.traceRays(base)
+    hit = o_ids[:, 0] >= 0
+    # second generation: leave the hit points at grazing angles (origin ON a surface, as every bounce ray is)
+    p = (o[hit] + d[hit] * o_tbg[hit, :1]).astype(np.float32)
+    m = p.shape[0]
+    g = unit(rng.normal(size=(m, 3)))
+    graze = unit(d[hit] + 1e-3 * g)  # continue almost along the incoming direction = almost tangent for grazing incidences
+    surf_a = np.concatenate([p, np.full((m, 1), 5e-5, np.float32), g, np.full((m, 1), 1e27, np.float32)], 1)
+    surf_b = np.concatenate([p, np.zeros((m, 1), np.float32), graze, np.full((m, 1), 1e27, np.float32)], 1)
+    attr, _ = app.geometry(0)
+    closest = np.concatenate([base, surf_a, surf_b]).astype(np.float32)
+    shadow = closest.copy()
+    shadow[:, 7] = rng.uniform(0.05, 6.0, shadow.shape[0]).astype(np.float32)
+
+    rec, inst, occ = dev.debugTraceQueue(closest, shadow)
+    o_tbg, o_ids = ref.traceRays(closest)
+    assert np.array_equal(inst, o_ids[:, 0]), f"{(inst != o_ids[:, 0]).sum()} instance ids differ"
+    hit = o_ids[:, 0] >= 0
+    assert hit.mean() > 0.2  # the open scenes let half of the rays escape
+    prim = slot_primitive[rec[hit, 3].view(np.int32)]
+    assert np.array_equal(prim, o_ids[hit, 1]), f"{(prim != o_ids[hit, 1]).sum()} primitive ids differ"
+    assert np.array_equal(_bits(rec[hit, :3]), _bits(o_tbg[hit])), "t / beta / gamma differ"
+    _, s_ids = ref.traceRays(shadow, anyHit=True)
+    assert np.array_equal(occ, s_ids[:, 0]), f"{(occ != s_ids[:, 0]).sum()} occlusion flags differ"
+    assert 0.02 < occ.mean() < 0.98
+    dev.close()

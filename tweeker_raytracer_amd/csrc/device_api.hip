@@ -1353,6 +1353,77 @@ try
 }
 TWK_CATCH("twk_trace_rays")
 
+int twk_debug_trace_queue(TwkDevice dev, const float* closestRays, size_t numClosest, const float* shadowRays, size_t numShadow,
+                          float* tBetaGammaSlot, int* instance, int* occluded)
+try
+{
+  int rc = activate(dev, "twk_debug_trace_queue"); if (rc) return rc;
+  if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_trace_queue: twk_build has not been called");
+  if ((numClosest && (!closestRays || !tBetaGammaSlot || !instance)) || (numShadow && (!shadowRays || !occluded))) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_trace_queue: NULL buffer");
+  for (const DevMaterial& m : dev->materials) if (m.textureCutout) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_trace_queue: geometric query only, not for scenes with cutout opacity");
+  const size_t n = std::max(numClosest, numShadow);
+  if (n == 0) return TWK_SUCCESS;
+  if (n >= ((size_t) 1 << 30)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_trace_queue: too many rays");
+  if (!dev->stateSet) { dev->launchWidth = 1; }
+  const size_t pixels = (size_t) dev->launchWidth * (size_t) dev->state.resolution[1];
+  if ((rc = ensureStreams(dev, (int) std::min<size_t>((n + pixels - 1) / pixels, (size_t) 1 << 30)))) return rc;
+  if ((size_t) dev->allocatedPaths < n) return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "twk_debug_trace_queue: path streams too small");
+  refreshParams(dev);
+  LaunchParams p = dev->params;
+  p.numPaths = dev->allocatedPaths; p.batchCount = 1; p.firstHit = nullptr; p.firstHitInstance = nullptr; p.stats = nullptr;
+  // the rays of one bounce: radiance rays in queue 1, the shadow rays "emitted by shade 0" in the shadow queue
+  std::vector<float4> org(n), dir(n);
+  std::vector<unsigned int> index(n);
+  for (size_t i = 0; i < n; ++i) index[i] = (unsigned int) i;
+  auto split = [&](const float* rays, size_t count)
+  {
+    for (size_t i = 0; i < count; ++i)
+    {
+      const float* r = rays + 8 * i;
+      org[i] = make_float4(r[0], r[1], r[2], r[3]); dir[i] = make_float4(r[4], r[5], r[6], r[7]);
+    }
+  };
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  HIP_TRY(hipMemset(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
+  if (numClosest)
+  {
+    split(closestRays, numClosest);
+    HIP_TRY(hipMemcpy(p.rayOrg[1], org.data(), numClosest * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.rayDir[1], dir.data(), numClosest * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.rayPixel[1], index.data(), numClosest * sizeof(unsigned int), hipMemcpyHostToDevice));
+    const unsigned int c = (unsigned int) numClosest;
+    HIP_TRY(hipMemcpy(dev->d_counters + 1 * TWK_COUNTERS_PER_DEPTH + 0, &c, sizeof(c), hipMemcpyHostToDevice));
+  }
+  if (numShadow)
+  {
+    split(shadowRays, numShadow);
+    std::vector<float4> pending(numShadow, make_float4(1.0f, 0.0f, 0.0f, 0.0f));
+    HIP_TRY(hipMemcpy(p.shadowOrg, org.data(), numShadow * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.shadowDir, dir.data(), numShadow * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.shadowPixel, index.data(), numShadow * sizeof(unsigned int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.shadowPending, pending.data(), numShadow * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(p.pathRadiance, 0, numShadow * sizeof(float4)));
+    const unsigned int c = (unsigned int) numShadow;
+    HIP_TRY(hipMemcpy(dev->d_counters + 0 * TWK_COUNTERS_PER_DEPTH + 1, &c, sizeof(c), hipMemcpyHostToDevice));
+  }
+  launchTrace(p, 1, false, traceGridBlocks(dev), dev->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (numClosest)
+  {
+    HIP_TRY(hipMemcpy(tBetaGammaSlot, p.hitRecord, numClosest * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(instance, p.hitInstance, numClosest * sizeof(int), hipMemcpyDeviceToHost));
+  }
+  if (numShadow)
+  {
+    std::vector<float4> radiance(numShadow);
+    HIP_TRY(hipMemcpy(radiance.data(), p.pathRadiance, numShadow * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < numShadow; ++i) occluded[i] = (radiance[i].x == 0.0f) ? 1 : 0; // an unoccluded shadow ray adds its pending contribution (1, 0, 0)
+  }
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_debug_trace_queue")
+
 int twk_debug_read_acceleration(TwkDevice dev, TwkAccelerationInfo* info, void* wideNodes, void* triangles, void* instances)
 try
 {

@@ -228,6 +228,19 @@ class Device:
         L.check(L.lib.twk_gather_peak(self._h, C.c_size_t(int(table_bytes)), C.byref(g)))
         return g.value
 
+    def debugTraceQueue(self, closest=None, shadow=None):
+        """One launch of the persistent traversal kernel over explicit rays ([n, 8] each; either may be None).
+        Returns (hit records float32 [n, 4] = t, beta, gamma, slot bits; instance int32 [n]; occluded int32 [m])."""
+        c = np.zeros((0, 8), np.float32) if closest is None else np.ascontiguousarray(closest, np.float32).reshape(-1, 8)
+        s = np.zeros((0, 8), np.float32) if shadow is None else np.ascontiguousarray(shadow, np.float32).reshape(-1, 8)
+        rec = np.zeros((max(1, c.shape[0]), 4), np.float32)
+        inst = np.full((max(1, c.shape[0]),), -1, np.int32)
+        occ = np.zeros((max(1, s.shape[0]),), np.int32)
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.check(L.lib.twk_debug_trace_queue(self._h, c.ctypes.data_as(fp), C.c_size_t(c.shape[0]), s.ctypes.data_as(fp), C.c_size_t(s.shape[0]),
+                                            rec.ctypes.data_as(fp), inst.ctypes.data_as(ip), occ.ctypes.data_as(ip)))
+        return rec[:c.shape[0]], inst[:c.shape[0]], occ[:s.shape[0]]
+
     def readAcceleration(self):
         """(info dict, wide nodes float32 [n, 32], triangle slots float32 [m, 12], instance records float32 [k, 32]) of the built scene."""
         info = L.AccelerationInfo()
