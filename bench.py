@@ -33,11 +33,11 @@ HBM_SPEC_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; the denomina
 
 # Algorithmic bytes of the traversal kernel, SURVEY.md §8(d)'s record table (cache hits do not reduce them):
 B_RAY_FIXED = 48      # 32 B ray record in + 16 B hit record out (shadow rays: 32 B ray + 16 B pending contribution)
-B_NODE = 128          # one 4-ary wide-node visit = two levels of §8(d)'s 64-byte binary nodes fetched at once
+B_NODE = 64           # one 4-ary wide-node visit: two levels of the binary tree in ONE 64-byte quantised record (device_types.h), the size of §8(d)'s binary node
 B_TRIANGLE = 48       # one Woop triangle slot (three float4)
 B_INSTANCE = 64       # instance entry (two-level scenes only): world-to-object rows + BVH root, what an IAS leaf hands an OptiX traversal
 # 16-byte lane loads the kernel issues per unit (what the divergent-gather ceiling prices)
-L_RAY, L_NODE, L_TRIANGLE, L_INSTANCE = 2, 8, 3, 4
+L_RAY, L_NODE, L_TRIANGLE, L_INSTANCE = 2, 4, 3, 4
 
 
 def weak_frame_for(n_gpus, base=(1920, 1080)):
@@ -301,14 +301,14 @@ def main():
             "frac": gather_gbps / (gather_peak * 16.0),
             "traffic": traffic,
             "traffic_note": traffic_note,
-            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued to the vector memory path (2 per ray, 8 per wide node NOT served by the LDS top-of-tree cache, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel beyond memory (vector issue at partial lane occupancy): DESIGN.md 4.1",
+            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued to the vector memory path (2 per ray, 4 per quantised wide node NOT served by the LDS top-of-tree cache, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel beyond memory (vector issue at partial lane occupancy): DESIGN.md 4.1",
             "fractions": fractions,
             "stream_peak_gbps_measured": stream_peak,
             "hbm_spec_gbps": HBM_SPEC_GBPS,
             "gather_peak_glaneloads_per_s_measured": gather_peak,
             "algorithmic_gbps": algo_gbps,
             "algorithmic_bytes_per_launch": algo_bytes / trace_launches,
-            "algorithmic_record_table": {"ray_in_hit_out": B_RAY_FIXED, "wide_node_visit(2 x 64 B binary levels)": B_NODE, "triangle": B_TRIANGLE, "instance_entry": B_INSTANCE},
+            "algorithmic_record_table": {"ray_in_hit_out": B_RAY_FIXED, "wide_node_visit(quantised 4-ary node, two binary levels)": B_NODE, "triangle": B_TRIANGLE, "instance_entry": B_INSTANCE},
             "avg_launch_ms": trace_ms / trace_launches,
             "launches": trace_launches,
             "rays_per_step": rays / args.steps,

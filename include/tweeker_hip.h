@@ -138,7 +138,7 @@ typedef struct TwkLaunchStats
 {
   uint64_t radianceRays;    /* closest-hit rays traced */
   uint64_t shadowRays;      /* any-hit rays traced */
-  uint64_t nodesVisited;    /* 4-ary wide nodes visited (128 B each), both ray kinds */
+  uint64_t nodesVisited;    /* 4-ary wide nodes visited (64 B quantised records), both ray kinds */
   uint64_t trianglesTested; /* triangle records fetched (48 B each) */
   uint64_t instancesEntered;
   uint64_t shadedHits;
@@ -154,6 +154,10 @@ typedef struct TwkLaunchStats
   uint64_t leafWaveSteps;     /* wave-level executions of the leaf / instance entry / instance exit step */
   uint64_t cachedNodesVisited; /* of nodesVisited: wide nodes served from the LDS top-of-tree cache, not from memory */
   uint64_t droppedStackPushes; /* single-ray fallback traversal: pushes beyond its LDS + HBM stack (a truncated traversal); 0 on every scene tried */
+  /* Where the waves of the persistent traversal kernel spend their time: shader-clock cycles (s_memtime, waits included)
+   * summed over all waves, per phase of the kernel's outer loop — [0] refill (ray fetch), [1] node loop, [2] leaf /
+   * instance step, [3] triangle loop, [4] pop + result write, [5] whole kernel. */
+  uint64_t waveCycles[6];
 } TwkLaunchStats;
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */
@@ -333,9 +337,11 @@ int twk_debug_trace_queue(TwkDevice dev, const float* closestRays, size_t numClo
 
 /* Read-back of the acceleration structure twk_build produced, for the same-BVH host walker of the test tooling
  * (oracle/same_bvh_walk.cpp: visit counts and a one-core traversal rate on exactly the tree the kernels walk).
- * Two-call protocol: with NULL buffers only `info` is filled. wideNodes: numNodes x 128 B (eight float4: lo_k.xyz, hi_k.xyz
- * of the four children, their references in the .w of the first four; reference >= 0 inner node, < 0 leaf with
- * payload ~ref = instance index, or first slot | (count - 1) << 28 [| 0x40000000 for world-space slots]);
+ * Two-call protocol: with NULL buffers only `info` is filled. wideNodes: numNodes x 64 B, the quantised 4-ary nodes the
+ * persistent kernel walks (four float4: origin.xyz, cell.x | cell.y, cell.z, qlo.x, qlo.y | qlo.z, qhi.x, qhi.y, qhi.z |
+ * four references; q words hold one byte per child, child box = origin + q * cell, an unused entry has the inverted box
+ * lo 255 / hi 0; reference >= 0 inner node, < 0 leaf with payload ~ref = instance index, or first slot | (count - 1) << 28
+ * [| 0x40000000 for world-space slots]);
  * triangles: numTriangleSlots x 48 B (three float4: vertex, .w = primitive index / instance index / 0);
  * instances: numInstances x 128 B (world-to-object 3x4, BVH root, ..., see csrc/device_types.h DevInstance). */
 typedef struct TwkAccelerationInfo

@@ -3,7 +3,8 @@
 // Same-BVH host walker (north_star: "a single-threaded C++ CPU fallback of the same kernels timed on the host cores";
 // "per-ray visit counts taken from the CPU fallback running the same BVH on the same rays"): walks the
 // acceleration structure the DEVICE built (read back through twk_debug_read_acceleration) with the per-ray algorithm
-// of the persistent traversal kernel (tweeker_raytracer_amd/csrc/trace_kernels.hip): 4-ary wide nodes, the four entry
+// of the persistent traversal kernel (tweeker_raytracer_amd/csrc/trace_kernels.hip): quantised 4-ary wide nodes (64 B,
+// child boxes on the 8-bit grid of the node's own box, decoded with the kernel's float expressions), the four entry
 // distances sorted by the same five compare-exchanges, nearest child next and the others pushed far to near,
 // flattened world-space leaves tested with the untransformed ray, instances entered through the world-to-object
 // matrix, the watertight Woop-Benthin-Wald triangle test with ties to the smaller (instance, primitive). It returns
@@ -33,16 +34,16 @@ inline void setupRay(Ray& r, const V3& o, const V3& d)
   r.id = v3(guardedReciprocal(d.x), guardedReciprocal(d.y), guardedReciprocal(d.z));
   r.ood = v3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
 }
-inline bool slabTest(const Ray& r, const float* lo, const float* hi, float tmin, float tmax, float& tnear)
+// trace_device.h slabTestGrid: plane distance of grid coordinate q = q * a + b, a = cell / d, b = (origin - o) / d;
+// qn / qf = coordinates of the plane the ray meets first / last on each axis
+inline bool slabTestGrid(const float a[3], const float b[3], const float qn[3], const float qf[3], float tmin, float tmax, float& tnear)
 {
-  const float x0 = fmaf(lo[0], r.id.x, -r.ood.x), x1 = fmaf(hi[0], r.id.x, -r.ood.x);
-  const float y0 = fmaf(lo[1], r.id.y, -r.ood.y), y1 = fmaf(hi[1], r.id.y, -r.ood.y);
-  const float z0 = fmaf(lo[2], r.id.z, -r.ood.z), z1 = fmaf(hi[2], r.id.z, -r.ood.z);
-  const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+  const float tn = fmaxf(fmaxf(fmaf(qn[0], a[0], b[0]), fmaf(qn[1], a[1], b[1])), fmaxf(fmaf(qn[2], a[2], b[2]), tmin));
+  const float tf = fminf(fminf(fmaf(qf[0], a[0], b[0]), fmaf(qf[1], a[1], b[1])), fminf(fmaf(qf[2], a[2], b[2]), tmax));
   tnear = tn;
   return tn * 0.9999975f <= tf * 1.0000025f;
 }
+inline unsigned int asUint(float f) { unsigned int i; memcpy(&i, &f, 4); return i; }
 
 struct Woop { int kx, ky, kz; float Sx, Sy, Sz; };
 inline void woopSetup(const V3& d, Woop& w)
@@ -110,14 +111,24 @@ int orc_walk_same_bvh(const float* wideNodes, int root, const float* triangles, 
     {
       if (node >= 0 && node != SENTINEL)
       {
-        const float* w = wideNodes + 32 * (size_t) node;
+        const float* w = wideNodes + 16 * (size_t) node;
         ++counts[0];
         float t[4]; int ref[4]; bool hit[4];
         int hits = 0;
+        const float a[3] = {w[3] * ray.id.x, w[4] * ray.id.y, w[5] * ray.id.z};
+        const float b[3] = {fmaf(w[0], ray.id.x, -ray.ood.x), fmaf(w[1], ray.id.y, -ray.ood.y), fmaf(w[2], ray.id.z, -ray.ood.z)};
+        const unsigned int qlo[3] = {asUint(w[6]), asUint(w[7]), asUint(w[8])}, qhi[3] = {asUint(w[9]), asUint(w[10]), asUint(w[11])};
+        const float idir[3] = {ray.id.x, ray.id.y, ray.id.z};
         for (int k = 0; k < 4; ++k)
         {
-          ref[k] = asInt(w[4 * k + 3]);
-          hit[k] = slabTest(ray, w + 8 * k, w + 8 * k + 4, tmin, bestT, t[k]);
+          ref[k] = asInt(w[12 + k]);
+          float qn[3], qf[3];
+          for (int c = 0; c < 3; ++c)
+          {
+            const float ql = (float) ((qlo[c] >> (8 * k)) & 0xffu), qh = (float) ((qhi[c] >> (8 * k)) & 0xffu);
+            qn[c] = (idir[c] < 0.0f) ? qh : ql; qf[c] = (idir[c] < 0.0f) ? ql : qh;
+          }
+          hit[k] = slabTestGrid(a, b, qn, qf, tmin, bestT, t[k]); // an unused entry has an inverted box: never entered
           if (!hit[k]) t[k] = INFINITY;
           hits += hit[k] ? 1 : 0;
         }

@@ -70,7 +70,7 @@ class LaunchStats(C.Structure):
                 ("tailNodesVisited", C.c_uint64), ("tailTrianglesTested", C.c_uint64), ("tailInstancesEntered", C.c_uint64),
                 ("overflowRays", C.c_uint64),
                 ("nodeWaveSteps", C.c_uint64), ("triangleWaveSteps", C.c_uint64), ("leafWaveSteps", C.c_uint64),
-                ("cachedNodesVisited", C.c_uint64), ("droppedStackPushes", C.c_uint64)]
+                ("cachedNodesVisited", C.c_uint64), ("droppedStackPushes", C.c_uint64), ("waveCycles", C.c_uint64 * 6)]
 
 
 class AccelerationInfo(C.Structure):

@@ -383,9 +383,67 @@ __global__ void emitTrianglesKernel(const float* __restrict__ attributes, const 
   out[7] = make_float4(c[10], c[11], 0.0f, 0.0f);
 }
 
-// Top-of-tree cache (device_types.h TWK_NODE_CACHED): breadth-first from the root over the wide nodes, the first
-// TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One thread: 16 nodes.
-__global__ void topCacheKernel(const BvhNode* __restrict__ wide, int root, float4* __restrict__ top)
+// Quantised copy of the wide nodes (device_types.h "quantised wide node"), one thread per inner node index. The grid
+// cell of an axis is the smallest power of two with extent / cell < 254; lo planes are rounded down and hi planes up,
+// and each is checked against the float expression the traversal evaluates (origin + q * cell).
+__global__ void quantizeWideKernel(const BvhNode* __restrict__ wide, float4* __restrict__ out, int count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float4* w = reinterpret_cast<const float4*>(wide + 2 * (size_t) i);
+  const float inf = __uint_as_float(0x7f800000u);
+  float lo[4][3], hi[4][3];
+  int ref[4];
+  bool valid[4];
+  float org[3] = {inf, inf, inf}, top[3] = {-inf, -inf, -inf};
+  for (int k = 0; k < 4; ++k)
+  {
+    const float4 a = w[2 * k], b = w[2 * k + 1];
+    lo[k][0] = a.x; lo[k][1] = a.y; lo[k][2] = a.z; hi[k][0] = b.x; hi[k][1] = b.y; hi[k][2] = b.z;
+    ref[k] = __float_as_int(w[k].w);
+    valid[k] = !(a.x == inf && b.x == inf); // emptyEntry
+    if (valid[k]) for (int c = 0; c < 3; ++c) { org[c] = fminf(org[c], lo[k][c]); top[c] = fmaxf(top[c], hi[k][c]); }
+  }
+  float cell[3];
+  unsigned int qlo[3] = {0u, 0u, 0u}, qhi[3] = {0u, 0u, 0u};
+  for (int c = 0; c < 3; ++c)
+  {
+    if (!(org[c] < inf)) org[c] = 0.0f; // no valid child (never visited)
+    const float extent = fmaxf(top[c] - org[c], 0.0f);
+    int e = -125;
+    if (extent > 0.0f && extent < inf) { frexpf(extent * (1.0f / 254.0f), &e); e = max(-125, min(126, e)); }
+    cell[c] = ldexpf(1.0f, e);
+    for (int k = 0; k < 4; ++k)
+    {
+      if (!valid[k]) { qlo[c] |= 255u << (8 * k); continue; } // unused entry: inverted box (lo = 255, hi = 0), never entered
+      int ql = (int) fminf(fmaxf(floorf((lo[k][c] - org[c]) / cell[c]), 0.0f), 255.0f);
+      int qh = (int) fminf(fmaxf(ceilf((hi[k][c] - org[c]) / cell[c]), 0.0f), 255.0f);
+      if (ql > 0 && __builtin_fmaf((float) ql, cell[c], org[c]) > lo[k][c]) --ql;
+      if (qh < 255 && __builtin_fmaf((float) qh, cell[c], org[c]) < hi[k][c]) ++qh;
+      qlo[c] |= (unsigned int) ql << (8 * k);
+      qhi[c] |= (unsigned int) qh << (8 * k);
+    }
+  }
+  float4* o = out + 4 * (size_t) i;
+  o[0] = make_float4(org[0], org[1], org[2], cell[0]);
+  o[1] = make_float4(cell[1], cell[2], __uint_as_float(qlo[0]), __uint_as_float(qlo[1]));
+  o[2] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[0]), __uint_as_float(qhi[1]), __uint_as_float(qhi[2]));
+  // an unused entry repeats the reference of the first child: should a degenerate node (no extent on any axis) let a ray
+  // into it after all, the ray walks a real subtree twice instead of following a wild reference
+  int first = 0;
+  while (first < 3 && !valid[first]) ++first;
+  o[3] = make_float4(__int_as_float(valid[0] ? ref[0] : ref[first]), __int_as_float(valid[1] ? ref[1] : ref[first]),
+                     __int_as_float(valid[2] ? ref[2] : ref[first]), __int_as_float(valid[3] ? ref[3] : ref[first]));
+}
+
+void launchQuantizeWide(const BvhNode* wide, float4* out, int count, hipStream_t stream)
+{
+  if (count > 0) hipLaunchKernelGGL(quantizeWideKernel, dim3((count + 255) / 256), dim3(256), 0, stream, wide, out, count);
+}
+
+// Top-of-tree cache (device_types.h TWK_NODE_CACHED): breadth-first from the root over the quantised wide nodes, the
+// first TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One thread: a few dozen nodes.
+__global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float4* __restrict__ top)
 {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int queue[TWK_TOP_NODES];
@@ -393,35 +451,33 @@ __global__ void topCacheKernel(const BvhNode* __restrict__ wide, int root, float
   queue[0] = root;
   for (int i = 0; i < n; ++i)
   {
-    const float4* w = reinterpret_cast<const float4*>(wide + 2 * (size_t) queue[i]);
+    const float4 refs = wideQ[4 * (size_t) queue[i] + 3];
+    const int r[4] = {__float_as_int(refs.x), __float_as_int(refs.y), __float_as_int(refs.z), __float_as_int(refs.w)};
+    const unsigned int qlx = __float_as_uint(wideQ[4 * (size_t) queue[i] + 1].z), qhx = __float_as_uint(wideQ[4 * (size_t) queue[i] + 2].y);
     for (int k = 0; k < 4; ++k)
     {
-      const int ref = __float_as_int(w[k].w);
-      if (ref >= 0 && ref != TWK_BVH_SENTINEL && n < TWK_TOP_NODES) queue[n++] = ref;
+      const bool unused = ((qlx >> (8 * k)) & 0xffu) > ((qhx >> (8 * k)) & 0xffu); // inverted box
+      if (!unused && r[k] >= 0 && r[k] != TWK_BVH_SENTINEL && n < TWK_TOP_NODES) queue[n++] = r[k];
     }
   }
   for (int i = 0; i < TWK_TOP_NODES; ++i)
   {
-    float4* out = top + 8 * i;
-    if (i >= n) { for (int k = 0; k < 8; ++k) out[k] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(~0)); continue; }
-    const float4* w = reinterpret_cast<const float4*>(wide + 2 * (size_t) queue[i]);
-    for (int k = 0; k < 8; ++k)
-    {
-      float4 v = w[k];
-      if (k < 4)
-      {
-        const int ref = __float_as_int(v.w);
-        if (ref >= 0)
-          for (int j = 0; j < n; ++j) if (queue[j] == ref) { v.w = __int_as_float(TWK_NODE_CACHED | j); break; }
-      }
-      out[k] = v;
-    }
+    float4* out = top + 4 * i;
+    if (i >= n) { for (int k = 0; k < 4; ++k) out[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; } // slot never referenced
+    const float4* w = wideQ + 4 * (size_t) queue[i];
+    for (int k = 0; k < 3; ++k) out[k] = w[k];
+    const float4 refs = w[3];
+    int r[4] = {__float_as_int(refs.x), __float_as_int(refs.y), __float_as_int(refs.z), __float_as_int(refs.w)};
+    for (int k = 0; k < 4; ++k)
+      if (r[k] >= 0 && r[k] != TWK_BVH_SENTINEL)
+        for (int j = 0; j < n; ++j) if (queue[j] == r[k]) { r[k] = TWK_NODE_CACHED | j; break; }
+    out[3] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(r[2]), __int_as_float(r[3]));
   }
 }
 
-void launchTopCache(const BvhNode* wide, int root, float4* top, hipStream_t stream)
+void launchTopCache(const float4* wideQ, int root, float4* top, hipStream_t stream)
 {
-  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wide, root, top);
+  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wideQ, root, top);
 }
 
 #define BVH_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)

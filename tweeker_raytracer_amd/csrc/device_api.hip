@@ -101,7 +101,7 @@ struct TwkDevice_t
   DevLight* d_lights = nullptr;
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
-  BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
+  BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
   float4* d_topNodes = nullptr; bool topCache = true; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
@@ -214,7 +214,7 @@ static int calculateShift(int size) // Device.cpp:1172-1189
 static void refreshParams(TwkDevice dev)
 {
   LaunchParams& p = dev->params;
-  p.nodes = dev->d_nodes; p.wideNodes = dev->d_wideNodes; p.triangles = dev->d_triangles; p.shadeTriangles = dev->d_shadeTriangles; p.instances = dev->d_instances;
+  p.nodes = dev->d_nodes; p.wideQ = dev->d_wideQ; p.triangles = dev->d_triangles; p.shadeTriangles = dev->d_shadeTriangles; p.instances = dev->d_instances;
   p.attributes = dev->d_attributes; p.indices = dev->d_indices;
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
@@ -254,7 +254,7 @@ static void refreshParams(TwkDevice dev)
   p.traceStackSpill = dev->d_spill;
 }
 
-static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * 6; } // 24 KiB LDS stack per block → 6 blocks per CU
+static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * TWK_TRACE_WAVES; } // every block resident at once (device_types.h)
 
 // `samples`: samples per pixel the next wavefront pass carries; the path streams grow to what passes actually need
 // (a 64-sample pass of a 1920x1080 frame takes 46 GB, a handle that renders two iterations takes 1.4 GB).
@@ -578,7 +578,7 @@ try
   for (TimedLaunch& t : dev->timed) { (void) hipEventDestroy(t.start); (void) hipEventDestroy(t.stop); }
   freeDevice(dev->d_camera); freeDevice(dev->d_lights); freeDevice(dev->d_materials);
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
-  freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
+  freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
   freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
@@ -880,11 +880,12 @@ try
   if (numTris >= ((size_t) 1 << 28) || numAttr >= ((size_t) 1 << 31) || numIdx >= ((size_t) 1 << 31))
     return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_build: " + std::to_string(numTris) + " triangle slots; a leaf reference holds 28 bits of slot index");
 
-  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
+  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   HIP_TRY(hipMalloc(&dev->d_attributes, sizeof(TwkTriangleAttributes) * numAttr));
   HIP_TRY(hipMalloc(&dev->d_indices, sizeof(unsigned int) * numIdx));
   HIP_TRY(hipMalloc(&dev->d_nodes, sizeof(BvhNode) * numNodes));
   HIP_TRY(hipMalloc(&dev->d_wideNodes, sizeof(BvhNode) * 2 * numNodes));
+  HIP_TRY(hipMalloc(&dev->d_wideQ, sizeof(float4) * 4 * numNodes));
   HIP_TRY(hipMalloc(&dev->d_triangles, sizeof(float4) * 3 * numTris));
   HIP_TRY(hipMalloc(&dev->d_shadeTriangles, sizeof(float4) * TWK_SHADE_RECORD * numTris));
   HIP_TRY(hipMalloc(&dev->d_instances, sizeof(DevInstance) * numInstances));
@@ -968,10 +969,13 @@ try
     HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), leafPayload.data(), numInstances, dev->d_nodes + tlasBase, dev->d_wideNodes + 2 * (size_t) tlasBase, tlasBase));
     dev->tlasRoot = tlasBase;
   }
-  if (!dev->d_topNodes) HIP_TRY(hipMalloc(&dev->d_topNodes, sizeof(float4) * 8 * TWK_TOP_NODES));
-  launchTopCache(dev->d_wideNodes, dev->tlasRoot, dev->d_topNodes, dev->stream);
+  // the persistent trace kernel reads the quantised copy of the wide nodes; the full-precision ones were scratch
+  launchQuantizeWide(dev->d_wideNodes, dev->d_wideQ, (int) numNodes, dev->stream);
+  if (!dev->d_topNodes) HIP_TRY(hipMalloc(&dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
+  launchTopCache(dev->d_wideQ, dev->tlasRoot, dev->d_topNodes, dev->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
+  freeDevice(dev->d_wideNodes);
 
   info.triangleSlots = numTris; info.nodes = numNodes; info.instances = (uint64_t) numInstances; info.flattenedInstances = (uint64_t) (numInstances - numEntered);
   info.buildMilliseconds = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
@@ -1236,6 +1240,7 @@ try
   stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
   stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
   stats->cachedNodesVisited = h[16]; stats->droppedStackPushes = h[17];
+  for (int i = 0; i < 6; ++i) stats->waveCycles[i] = h[18 + i];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }
@@ -1433,7 +1438,7 @@ try
   info->root = dev->tlasRoot; info->twoLevel = dev->twoLevel ? 1 : 0;
   info->numNodes = dev->totalNodes; info->numTriangleSlots = dev->totalTriangles; info->numInstances = dev->instances.size();
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, dev->d_wideNodes, sizeof(BvhNode) * 2 * dev->totalNodes, hipMemcpyDeviceToHost));
+  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, dev->d_wideQ, sizeof(float4) * 4 * dev->totalNodes, hipMemcpyDeviceToHost));
   if (triangles) HIP_TRY(hipMemcpy(triangles, dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles, hipMemcpyDeviceToHost));
   if (instances) HIP_TRY(hipMemcpy(instances, dev->d_instances, sizeof(DevInstance) * dev->instances.size(), hipMemcpyDeviceToHost));
   return TWK_SUCCESS;

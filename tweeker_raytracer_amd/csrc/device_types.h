@@ -110,26 +110,35 @@ struct __attribute__((aligned(16))) BvhNode
 
 #define TWK_BVH_SENTINEL 0x7fffffff
 
+// Quantised wide node of the persistent trace kernel, 64 bytes = four float4 (bvh_build.hip quantizeWideKernel):
+//   [0] origin.xyz, cell.x      origin = lower corner of the union of the child boxes, cell = a power of two per axis
+//   [1] cell.y, cell.z, qlo.x, qlo.y     q words: one byte per child (child k in bits 8k..8k+7)
+//   [2] qlo.z, qhi.x, qhi.y, qhi.z       child box = origin + q * cell, rounded outwards (lo down, hi up)
+//   [3] the four child references; an unused entry has the inverted box lo = 255, hi = 0 (its near planes lie behind
+//       its far planes for every ray) and repeats the first child's reference
+// Why 64 instead of the 128 bytes of full-precision boxes: a CU's vector memory path takes ONE divergent 16-byte lane
+// address per clock (tools/gather_probe2.hip) and the traversal is bound by it, not by arithmetic — the boxes only cull,
+// so precision can be traded for loads; the grid is 1/254 of the node's extent per axis, a few per cent more node visits.
+
 // Top-of-tree cache of the persistent trace kernel: the first TWK_TOP_NODES wide nodes in breadth-first order from the
 // root (every ray visits them) are copied into LDS by each block. A reference TWK_NODE_CACHED | slot names a cached
 // node; only the cached copies and LaunchParams::topRoot carry such references, the node arrays in HBM never do.
-// Why: a CU's vector memory path takes ONE divergent 16-byte lane address per clock (tools/gather_probe2.hip), a
-// wide-node fetch is eight of them per lane, and the kernel runs at 0.93 of that ceiling; the same fetch from LDS
-// (144-byte slot stride: 16 consecutive slots fall into disjoint bank windows) costs an eighth. Measured on C2: 16 slots -8.7 % kernel time, 32 slots a further -1.2 %.
+// The same fetch from LDS (80-byte slot stride: 16 consecutive slots fall into disjoint bank windows) costs a fraction
+// of the lane-address slots. Measured on C2 with 128-byte nodes: 16 slots -8.7 % kernel time, 32 slots a further -1.2 %.
 #define TWK_NODE_CACHED 0x20000000
 #ifndef TWK_TOP_NODES
-#define TWK_TOP_NODES 32
+#define TWK_TOP_NODES 64
 #endif
-#define TWK_TOP_STRIDE 9 // float4 per cached node (8 used)
+#define TWK_TOP_STRIDE 5 // float4 per cached node (4 used)
 
 // Everything a kernel needs; passed by value (≙ SystemData, shaders/system_data.h:40-90).
 struct LaunchParams
 {
   // scene
   const BvhNode*     nodes;          // binary nodes (single-ray traversal: query kernel, overflow fallback, tail kernel)
-  const float4*      topNodes;       // TWK_TOP_NODES x 8 float4: the cached top of the tree (device_types.h TWK_NODE_CACHED), built by twk_build
+  const float4*      topNodes;       // TWK_TOP_NODES x 4 float4: the cached top of the tree (device_types.h TWK_NODE_CACHED), built by twk_build
   int                topRoot;        // reference the persistent kernel starts at: TWK_NODE_CACHED | 0, or tlasRoot when the cache is off
-  const BvhNode*     wideNodes;      // 4-ary nodes, 128 bytes = 2 BvhNode slots per inner node index (persistent trace kernel; layout: bvh_build.hip writeWideNode)
+  const float4*      wideQ;          // quantised 4-ary nodes, 64 bytes = 4 float4 per inner node index (persistent trace kernel; layout above)
   const float4*      triangles;      // 3 per triangle slot
   const float4*      shadeTriangles; // TWK_SHADE_RECORD (8) per triangle slot, 128 B: geometric normal + the three vertices' normals | tangents | texcoords (bvh_build.hip emitTrianglesKernel)
   const DevInstance* instances;
@@ -200,7 +209,13 @@ struct LaunchParams
 #define TWK_MAX_DEPTH 64
 
 #ifndef TWK_TRACE_STACK_LDS
-#define TWK_TRACE_STACK_LDS   20  // entries per lane in LDS (21 KiB per block + 4.5 KiB top-of-tree cache: 6 blocks per CU)
+#define TWK_TRACE_STACK_LDS   20  // entries per lane in LDS
+#endif
+// Blocks of the persistent trace kernel per CU (= waves per SIMD, the grid is numCUs x this). LDS per block: 21 KiB of
+// traversal stacks + 5 KiB top-of-tree cache = 26 KiB, six of them in a CU's 160 KiB. Measured on C2 with every block
+// resident: 4 / 5 / 6 blocks per CU = 0.94 / 0.88 / 0.84 ms per step.
+#ifndef TWK_TRACE_WAVES
+#define TWK_TRACE_WAVES 6
 #endif
 #define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
 #define TWK_TRACE_BLOCK       256

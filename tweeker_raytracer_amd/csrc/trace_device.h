@@ -43,6 +43,20 @@ TWK_D bool slabTest(const TraceRay& r, float lox, float loy, float loz, float hi
   return tn * 0.9999975f <= tf * 1.0000025f;
 }
 
+// The same test on a quantised wide node (device_types.h): the planes of a child box are grid coordinates q of the
+// node's own box, plane distance = q * a + b with a = cell / d and b = (origin - o) / d per axis; qn / qf are the
+// coordinates of the plane the ray meets first / last on each axis (chosen by the caller from the sign of d). Three
+// roundings instead of one per plane; the build pads every box by 2^-17 of the scene scale (bvh_build.hip padBox),
+// which dwarfs them.
+TWK_D bool slabTestGrid(float ax, float ay, float az, float bx, float by, float bz,
+                        float qnx, float qny, float qnz, float qfx, float qfy, float qfz, float tmin, float tmax, float& tnear)
+{
+  const float tn = fmaxf(fmaxf(__builtin_fmaf(qnx, ax, bx), __builtin_fmaf(qny, ay, by)), fmaxf(__builtin_fmaf(qnz, az, bz), tmin));
+  const float tf = fminf(fminf(__builtin_fmaf(qfx, ax, bx), __builtin_fmaf(qfy, ay, by)), fminf(__builtin_fmaf(qfz, az, bz), tmax));
+  tnear = tn;
+  return tn * 0.9999975f <= tf * 1.0000025f;
+}
+
 // Woop-Benthin-Wald ray constants. The axis permutation (kx, ky, kz) is a cyclic shift of (x, y, z) chosen by the
 // dominant direction axis kz, with kx and ky exchanged when d[kz] < 0; it is kept as three flag bits in one register
 // (lane flags held as bools live in scalar masks and cost scalar merge instructions at the end of every divergent

@@ -80,17 +80,14 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // TWO_LEVEL = false: every instance of the scene is flattened (device_types.h TWK_LEAF_WORLD) — one world-space tree,
 // every leaf a triangle range; the instance entry / exit code is compiled out.
 template<bool COUNT, bool CUTOUT, bool TWO_LEVEL>
-#ifndef TWK_TRACE_WAVES
-#define TWK_TRACE_WAVES 6
-#endif
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // waves/SIMD; 21 KiB of LDS stacks + 4.5 KiB top-of-tree cache per block admit 6 blocks per CU
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
   __shared__ int stackStorage[(TWK_TRACE_STACK_LDS + 1) * TWK_TRACE_BLOCK]; // + 1 dummy row, see the node step
   __shared__ float4 topCache[TWK_TOP_NODES * TWK_TOP_STRIDE];               // device_types.h TWK_NODE_CACHED
   int* ldsStack = stackStorage + threadIdx.x;
   const int stride = TWK_TRACE_BLOCK;
-  if (threadIdx.x < TWK_TOP_NODES * 8) topCache[(threadIdx.x >> 3) * TWK_TOP_STRIDE + (threadIdx.x & 7)] = p.topNodes[threadIdx.x];
+  for (int i = threadIdx.x; i < TWK_TOP_NODES * 4; i += TWK_TRACE_BLOCK) topCache[(i >> 2) * TWK_TOP_STRIDE + (i & 3)] = p.topNodes[i];
   __syncthreads();
 
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
@@ -105,6 +102,11 @@ traceKernel(LaunchParams p, int depth)
   unsigned int nodeCount = 0, triCount = 0, instCount = 0, closestCount = 0, shadowCount = 0, maxSteps = 0, cachedCount = 0;
   unsigned int nodeWaveSteps = 0, triWaveSteps = 0, leafWaveSteps = 0; // COUNT: wave-level iterations, tallied by the first active lane (lane occupancy = lane count / (64 * wave steps))
 #define TWK_WAVE_STEP(counter) if (COUNT) { if (lane == (unsigned int) (__ffsll((long long) __ballot(true)) - 1)) ++(counter); }
+  // COUNT: wave time per phase of the outer loop (TwkLaunchStats::waveCycles), shader clock, wave-uniform
+  unsigned long long phaseCycles[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long phaseMark = COUNT ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long kernelStart = phaseMark;
+#define TWK_PHASE_END(k) if (COUNT) { const unsigned long long now_ = __builtin_readcyclecounter(); phaseCycles[k] += now_ - phaseMark; phaseMark = now_; }
 
   // Wave-uniform pool of queue slots. Most of the queue is handed out statically: wave w owns the contiguous range
   // [w * S, (w + 1) * S) with S = 3/4 of its fair share (a multiple of 64), the last quarter is dealt dynamically in
@@ -153,6 +155,14 @@ traceKernel(LaunchParams p, int depth)
   for (;;)
   {
     // ---- refill idle lanes from the wave's pool ------------------------------------------------------
+    // The wave waits here for the ray records it fetches (27 % of all wave time on C2, TwkLaunchStats::waveCycles) — and
+    // that is the cheapest form found. Built and measured: (a) issuing the loads here and setting the rays up behind the
+    // next node loop — whatever the source says, the register allocator moves a loaded value to its home right behind
+    // the load, with the wait; (b) a per-wave ring of prefetched records in LDS filled by global_load_lds_dwordx4 (no
+    // register, no compiler wait; as inline asm, since with the builtin hipcc drains the transfer in front of every
+    // flat_load of the node loop): refill share of wave time 27 % -> 12 %, kernel time unchanged at equal occupancy and
+    // 8 KiB of LDS per block dearer, i.e. 4 blocks per CU instead of 6: 0.96 against 0.84 ms per step. The other waves of
+    // the SIMD already cover this wait.
     {
       const unsigned long long idle = __ballot(!(state & ST_HAS_RAY));
       if (idle != 0ull && !exhausted)
@@ -194,7 +204,7 @@ traceKernel(LaunchParams p, int depth)
         continue; // pool was empty and the new ticket arrives next round
       }
     }
-
+    TWK_PHASE_END(0)
     // ---- traverse until enough lanes have finished to be worth a refill ------------------------------
     for (;;)
     {
@@ -205,34 +215,56 @@ traceKernel(LaunchParams p, int depth)
       // spilling traverse() (cold path, not taken on the LBVHs of the shipped scenes).
       while ((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
-        // one WIDE node = the four grandchildren of binary node `node`: two levels per round of loads
-        float4 l0, u0, l1, u1, l2, u2, l3, u3;
+        // one WIDE node = the four grandchildren of binary node `node` (two levels of the binary tree per round of
+        // loads), 64 bytes: child boxes as 8-bit grid coordinates of the node's own box (device_types.h "quantised wide
+        // node") — FOUR 16-byte lane loads instead of eight; the CU's vector memory path takes one divergent lane
+        // address per clock and this kernel is bound by it (doubling the loads of the uncached nodes: +57 % time, 64
+        // more VALU instructions per step: +6 %).
+        float4 n0, n1, n2, n3;
         // hipcc merges the two branches into ONE set of flat_load instructions on a selected generic pointer, and that is the
-        // faster form: forcing eight ds_read for the cached lanes and eight global_load for the others (empty asm pins in
+        // faster form: forcing ds_read for the cached lanes and global_load for the others (empty asm pins in
         // both branches) serialises two waits per step for a wave whose lanes are on both sides — 0.794 -> 0.878 ms/step.
         if (node & TWK_NODE_CACHED)
         {
           const float4* w = topCache + (node & 0xff) * TWK_TOP_STRIDE; // the top of the tree, from LDS
           if (COUNT) ++cachedCount;
-          l0 = w[0]; u0 = w[1]; l1 = w[2]; u1 = w[3]; l2 = w[4]; u2 = w[5]; l3 = w[6]; u3 = w[7];
+          n0 = w[0]; n1 = w[1]; n2 = w[2]; n3 = w[3];
         }
         else
         {
-          const float4* w = reinterpret_cast<const float4*>(p.wideNodes + 2 * (size_t) node);
-          l0 = w[0]; u0 = w[1]; l1 = w[2]; u1 = w[3]; l2 = w[4]; u2 = w[5]; l3 = w[6]; u3 = w[7];
+          const float4* w = p.wideQ + 4 * (size_t) node;
+          n0 = w[0]; n1 = w[1]; n2 = w[2]; n3 = w[3];
         }
         ++guard;
         if (COUNT) ++nodeCount;
         TWK_WAVE_STEP(nodeWaveSteps)
-        int r0 = __float_as_int(l0.w), r1 = __float_as_int(u0.w), r2 = __float_as_int(l1.w), r3 = __float_as_int(u1.w);
-        // Pin the references here: left alone, hipcc narrows the node loads to dwordx3 and fetches the four references
-        // with separate dword loads AFTER the box tests — two more dependent L2 round trips per traversal step.
+        int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y), r2 = __float_as_int(n3.z), r3 = __float_as_int(n3.w);
+        // Pin the references here: left alone, hipcc fetches them with separate loads AFTER the box tests — more
+        // dependent L2 round trips per traversal step.
         asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        // plane distance of grid coordinate q on one axis: (origin + q * cell - o) / d = q * (cell / d) + (origin / d - o / d)
+        const float ax = n0.w * ray.id.x, ay = n1.x * ray.id.y, az = n1.y * ray.id.z;
+        const float bx = __builtin_fmaf(n0.x, ray.id.x, -ray.ood.x), by = __builtin_fmaf(n0.y, ray.id.y, -ray.ood.y), bz = __builtin_fmaf(n0.z, ray.id.z, -ray.ood.z);
+        // Near and far plane of each axis by the sign of the ray direction, chosen ONCE for the four children (their grid
+        // coordinates share a word) — six selects instead of a min and a max per plane pair, 24 of them. (Vector
+        // instructions other than fma / mul / add cost 1.6 x an fma on this chip, tools/probes/valu_issue_probe.hip, and
+        // the node step is bound by their issue.) An unused entry has an inverted box (bvh_build.hip quantizeWideKernel):
+        // its near planes lie behind its far planes for every ray.
+        const bool negX = ray.id.x < 0.0f, negY = ray.id.y < 0.0f, negZ = ray.id.z < 0.0f;
+        const unsigned int qlx = __float_as_uint(n1.z), qly = __float_as_uint(n1.w), qlz = __float_as_uint(n2.x);
+        const unsigned int qhx = __float_as_uint(n2.y), qhy = __float_as_uint(n2.z), qhz = __float_as_uint(n2.w);
+        const unsigned int qnx = negX ? qhx : qlx, qfx = negX ? qlx : qhx;
+        const unsigned int qny = negY ? qhy : qly, qfy = negY ? qly : qhy;
+        const unsigned int qnz = negZ ? qhz : qlz, qfz = negZ ? qlz : qhz;
         float t0, t1, t2, t3;
-        const bool h0 = slabTest(ray, l0.x, l0.y, l0.z, u0.x, u0.y, u0.z, tmin, res.t, t0);
-        const bool h1 = slabTest(ray, l1.x, l1.y, l1.z, u1.x, u1.y, u1.z, tmin, res.t, t1);
-        const bool h2 = slabTest(ray, l2.x, l2.y, l2.z, u2.x, u2.y, u2.z, tmin, res.t, t2);
-        const bool h3 = slabTest(ray, l3.x, l3.y, l3.z, u3.x, u3.y, u3.z, tmin, res.t, t3);
+#define TWK_Q(word, k) ((float) (((word) >> (8 * (k))) & 0xffu)) /* v_cvt_f32_ubyte<k> */
+#define TWK_SLAB(k, tk) slabTestGrid(ax, ay, az, bx, by, bz, TWK_Q(qnx, k), TWK_Q(qny, k), TWK_Q(qnz, k), TWK_Q(qfx, k), TWK_Q(qfy, k), TWK_Q(qfz, k), tmin, res.t, tk)
+        const bool h0 = TWK_SLAB(0, t0);
+        const bool h1 = TWK_SLAB(1, t1);
+        const bool h2 = TWK_SLAB(2, t2);
+        const bool h3 = TWK_SLAB(3, t3);
+#undef TWK_SLAB
+#undef TWK_Q
         const float inf = __uint_as_float(0x7f800000u);
         t0 = h0 ? t0 : inf; t1 = h1 ? t1 : inf; t2 = h2 ? t2 : inf; t3 = h3 ? t3 : inf;
         // sort the four (entry distance, reference) pairs, misses last: 5 compare-exchanges
@@ -264,6 +296,7 @@ traceKernel(LaunchParams p, int depth)
         if (__popcll(__ballot((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_DEN < roundActive * TWK_TRACE_NODE_NUM) break;
       }
 
+      TWK_PHASE_END(1)
       // one leaf / instance-entry / instance-exit step per lane; lanes that left the node loop early are still
       // at an inner node and must NOT take this path (their `node` is not a leaf reference)
       unsigned int pop = 0u; // lane flag kept in a vector register, like `state`
@@ -326,6 +359,7 @@ traceKernel(LaunchParams p, int depth)
 
       }
 
+      TWK_PHASE_END(2)
       // ---- triangle phase -----------------------------------------------------------------------------------------
 #define TWK_MERGE_HIT(hit_, t_, beta_, gamma_, inst_, prim_, ts_)                                                              \
       {                                                                                                                        \
@@ -352,6 +386,7 @@ traceKernel(LaunchParams p, int depth)
         TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts)
       }
 #undef TWK_MERGE_HIT
+      TWK_PHASE_END(3)
 
       if (pop)
       {
@@ -405,6 +440,8 @@ traceKernel(LaunchParams p, int depth)
           if (res.instance < 0)
           {
             // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)
+            // (Three global_atomic_add_f32 without return instead of this read-modify-write — bit-identical, the hardware add
+            // rounds to nearest even and keeps subnormals, tools/probes/atomic_denorm_probe.hip — measured: kernel +4 %.)
             const unsigned int s = slot - numClosest;
             const unsigned int pixel = p.shadowPixel[s];
             const float4 c = p.shadowPending[s];
@@ -415,6 +452,7 @@ traceKernel(LaunchParams p, int depth)
         }
       }
 
+      TWK_PHASE_END(4)
       const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
       if (active == 0ull) break;
       if (!exhausted && __popcll(active) < min(TWK_TRACE_REFILL, (int) ticketSize)) break;
@@ -433,8 +471,14 @@ traceKernel(LaunchParams p, int depth)
     if (triWaveSteps)  atomicAdd(&p.stats[14], (unsigned long long) triWaveSteps);
     if (leafWaveSteps) atomicAdd(&p.stats[15], (unsigned long long) leafWaveSteps);
     if (cachedCount)   atomicAdd(&p.stats[16], (unsigned long long) cachedCount);
+    if (lane == 0)
+    {
+      for (int k = 0; k < 5; ++k) atomicAdd(&p.stats[18 + k], phaseCycles[k]);
+      atomicAdd(&p.stats[23], (unsigned long long) __builtin_readcyclecounter() - kernelStart);
+    }
   }
 #undef TWK_WAVE_STEP
+#undef TWK_PHASE_END
 }
 
 // Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again

@@ -215,7 +215,7 @@ class Device:
     def statsGet(self, reset=True):
         s = L.LaunchStats()
         L.check(L.lib.twk_stats_get(self._h, C.byref(s), int(bool(reset))))
-        return {name: getattr(s, name) for name, _ in L.LaunchStats._fields_}
+        return {name: (list(getattr(s, name)) if name == "waveCycles" else getattr(s, name)) for name, _ in L.LaunchStats._fields_}
 
     def streamPeakGBps(self, nbytes=1 << 30, repeats=10):
         g = C.c_float(0)
@@ -242,10 +242,10 @@ class Device:
         return rec[:c.shape[0]], inst[:c.shape[0]], occ[:s.shape[0]]
 
     def readAcceleration(self):
-        """(info dict, wide nodes float32 [n, 32], triangle slots float32 [m, 12], instance records float32 [k, 32]) of the built scene."""
+        """(info dict, quantised wide nodes float32 [n, 16], triangle slots float32 [m, 12], instance records float32 [k, 32]) of the built scene."""
         info = L.AccelerationInfo()
         L.check(L.lib.twk_debug_read_acceleration(self._h, C.byref(info), None, None, None))
-        nodes = np.zeros((info.numNodes, 32), np.float32)
+        nodes = np.zeros((info.numNodes, 16), np.float32)  # quantised wide nodes, 64 B
         tris = np.zeros((info.numTriangleSlots, 12), np.float32)
         inst = np.zeros((info.numInstances, 32), np.float32)
         L.check(L.lib.twk_debug_read_acceleration(self._h, C.byref(info), nodes.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p),
