@@ -9,7 +9,7 @@ NAME=$1; shift
 cd "$(dirname "$0")/../tweeker_raytracer_amd/csrc"
 make -s > /dev/null
 mkdir -p ../../build/$NAME
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-function"
 for f in trace_kernels tail_kernel bvh_build bvh_sah device_api shade_kernels; do
   hipcc $FLAGS "$@" -c $f.hip -o ../../build/$NAME/$f.o 2>&1 | grep -E "error" || true
 done

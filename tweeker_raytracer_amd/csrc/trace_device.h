@@ -65,23 +65,26 @@ TWK_D bool slabTestGrid(float ax, float ay, float az, float bx, float by, float 
 // test was 490 instructions long, most of them scalar.)
 struct WoopConstants
 {
-  unsigned int perm; // bit 0: kz == 0, bit 1: kz == 1, bit 2: d[kz] < 0 (kx and ky exchanged)
+  unsigned int perm; // bit 0: kz == 0, bit 1: kz == 1
   float Sx, Sy, Sz;
 };
 
-struct WoopPermutation { bool zIsX, zIsY, flip; };
-TWK_D WoopPermutation woopFlags(unsigned int perm) { WoopPermutation f; f.zIsX = (perm & 1u) != 0u; f.zIsY = (perm & 2u) != 0u; f.flip = (perm & 4u) != 0u; return f; }
+struct WoopPermutation { bool zIsX, zIsY; };
+TWK_D WoopPermutation woopFlags(unsigned int perm) { WoopPermutation f; f.zIsX = (perm & 1u) != 0u; f.zIsY = (perm & 2u) != 0u; return f; }
 
-// (v[kx], v[ky], v[kz]) of the permutation described by w.
+// (v[kx], v[ky], v[kz]) of the cyclic permutation described by w.
 TWK_D void woopPermute(const WoopPermutation& w, const V3& v, float& vx, float& vy, float& vz)
 {
-  const float c0 = w.zIsX ? v.y : (w.zIsY ? v.z : v.x);
-  const float c1 = w.zIsX ? v.z : (w.zIsY ? v.x : v.y);
-  vz             = w.zIsX ? v.x : (w.zIsY ? v.y : v.z);
-  vx = w.flip ? c1 : c0;
-  vy = w.flip ? c0 : c1;
+  vx = w.zIsX ? v.y : (w.zIsY ? v.z : v.x);
+  vy = w.zIsX ? v.z : (w.zIsY ? v.x : v.y);
+  vz = w.zIsX ? v.x : (w.zIsY ? v.y : v.z);
 }
 
+// The paper (and the oracle, oracle/orc_trace.h) exchanges kx and ky when d[kz] < 0 to keep the winding of the sheared
+// triangle. Nothing here culls by winding, and the exchange changes no result bit: with x and y exchanged every edge
+// function is the exact negation (U = Cx*By - Cy*Bx becomes Cy*Bx - Cx*By, also in the double-precision fallback), so
+// det and T change sign together and t = T / det, beta = V / det, gamma = W / det and every sign test come out the
+// same. It is left out: six selects per triangle test (selects cost 1.6 x an fma, tools/probes/valu_issue_probe.hip).
 TWK_D void woopSetup(const V3& d, WoopConstants& w)
 {
   const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
@@ -89,14 +92,11 @@ TWK_D void woopSetup(const V3& d, WoopConstants& w)
   WoopPermutation f;
   f.zIsX = (ax > ay) & (ax > az);
   f.zIsY = !(ax > ay) & (ay > az);
-  f.flip = false;
   float dx, dy, dz;
   woopPermute(f, d, dx, dy, dz);
-  f.flip = dz < 0.0f; // swap kx and ky: keeps the winding of the sheared triangle
-  w.perm = (f.zIsX ? 1u : 0u) | (f.zIsY ? 2u : 0u) | (f.flip ? 4u : 0u);
-  const float sx = f.flip ? dy : dx, sy = f.flip ? dx : dy;
-  w.Sx = sx / dz;
-  w.Sy = sy / dz;
+  w.perm = (f.zIsX ? 1u : 0u) | (f.zIsY ? 2u : 0u);
+  w.Sx = dx / dz;
+  w.Sy = dy / dz;
   w.Sz = 1.0f / dz;
 }
 
