@@ -301,7 +301,7 @@ def main():
             "frac": gather_gbps / (gather_peak * 16.0),
             "traffic": traffic,
             "traffic_note": traffic_note,
-            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued to the vector memory path (2 per ray, 4 per quantised wide node NOT served by the LDS top-of-tree cache, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel beyond memory (vector issue at partial lane occupancy): DESIGN.md 4.1",
+            "note": "memory-side roofline of an L2-resident gather workload: achieved = 16-byte lane loads issued to the vector memory path (2 per ray, 4 per quantised wide node NOT served by the LDS top-of-tree cache, 3 per triangle, 4 per instance entry) x 16 B / traversal kernel time; peak = the chip's divergent-gather ceiling measured in this run (twk_gather_peak, 32 MB table). Against the measured HBM stream-copy peak the SURVEY 8(d) algorithmic bytes give fractions.algorithmic_bytes_vs_stream_peak (cache hits included, can exceed 1) and the PMC bytes fractions.hbm_side_bytes_vs_stream_peak; what bounds the kernel is vector-instruction issue at partial lane occupancy, not memory (fractions.valu_issue_utilisation_pmc, wave_time_shares; sensitivity experiments and the per-instruction issue costs of tools/probes/valu_issue_probe.hip in DESIGN.md 4.1): the node record was halved to 64 B this round because loads were the cheaper thing to remove, which lowers `achieved` without lowering the rate",
             "fractions": fractions,
             "stream_peak_gbps_measured": stream_peak,
             "hbm_spec_gbps": HBM_SPEC_GBPS,
@@ -321,6 +321,9 @@ def main():
                                "node_wave_steps_per_launch": st["nodeWaveSteps"] / trace_launches,
                                "triangle_wave_steps_per_launch": st["triangleWaveSteps"] / trace_launches,
                                "leaf_wave_steps_per_launch": st["leafWaveSteps"] / trace_launches},
+            # where the waves of the kernel spend their time (shader-clock cycles summed over waves, waits included; counting variant of the kernel)
+            "wave_time_shares": {n: st["waveCycles"][k] / max(1, st["waveCycles"][5]) for k, n in
+                                 enumerate(["refill_ray_fetch", "node_loop", "leaf_or_instance_step", "triangle_loop", "pop_and_result_write"])},
             "Mrays_per_s": rays / trace_s / 1.0e6,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         }

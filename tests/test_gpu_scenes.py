@@ -8,6 +8,8 @@
   C5   the 3840x2160 frame tiled over 8 device indices (launchWidth 480): crop parity of one tile set
   compositor kernel
 """
+import sys
+
 import numpy as np
 import pytest
 
@@ -496,3 +498,85 @@ def test_build_quality_and_top_cache_do_not_change_hit_records(twk, orc, monkeyp
         assert np.array_equal(_bits(g_tbg[hit]), _bits(o_tbg[hit]))
         assert np.array_equal(_bits(dev.getOutputBufferHost()), _bits(ref.getOutputBufferHost()))
         dev.close()
+
+
+def _decode_children(node):
+    """(lo[4,3], hi[4,3], refs[4], unused[4]) of one 64-byte quantised wide node (csrc/device_types.h), float32 arithmetic as the kernel's planes."""
+    origin = node[0:3].astype(np.float32)
+    cell = node[3:6].astype(np.float32)
+    words = node[6:12].view(np.uint32)
+    refs = node[12:16].view(np.int32)
+    lo = np.zeros((4, 3), np.float32)
+    hi = np.zeros((4, 3), np.float32)
+    for k in range(4):
+        ql = np.array([(int(words[c]) >> (8 * k)) & 0xff for c in range(3)], np.float32)
+        qh = np.array([(int(words[3 + c]) >> (8 * k)) & 0xff for c in range(3)], np.float32)
+        lo[k] = origin + ql * cell
+        hi[k] = origin + qh * cell
+    unused = lo[:, 0] > hi[:, 0]
+    return lo, hi, refs, unused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_file", ["scene_rtigo3_cornell_box.txt", "scene_rtigo3_instances.txt"])
+def test_quantised_boxes_contain_everything_below_them(twk, scene_file):
+    """The boxes of the quantised wide nodes only cull, so all that matters is that they are conservative: walked from the
+    root (and from the BVH root of every entered instance), each decoded child box contains every triangle slot — or,
+    at the top level, the object-to-world image of the instance's own root box — below that child. Unused entries are
+    inverted boxes. Checked on the tree twk_build produced (twk_debug_read_acceleration), float32 as the kernel decodes it."""
+    from conftest import scene_path
+    system = "\n".join(["resolution 64 40", "tileSize 8 8", "samplesSqrt 1", "miss 0", "light 0", "pathLengths 1 1", "epsilonFactor 500",
+                        "lensShader 0", "center 0 1 0", "camera 0.75 0.5 45 3.41"]) + "\n"
+    app = twk.Application(system_text=system, scene_text=open(scene_path(scene_file)).read())
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    info, nodes, tris, inst = dev.readAcceleration()
+    dev.close()
+    verts = tris.reshape(-1, 3, 4)[:, :, :3]
+    slot_lo, slot_hi = verts.min(axis=1), verts.max(axis=1)
+    sys.setrecursionlimit(100000)
+    checked = {"nodes": 0, "leaves": 0, "unused": 0, "instances": 0}
+    roots_done = set()
+
+    def subtree_bounds(ref, top_level):
+        """bounds of the geometry below reference `ref`, in the space the reference lives in"""
+        if ref >= 0:
+            return node_bounds(ref, top_level)
+        payload = ~int(ref)
+        if top_level and not (payload & 0x40000000):
+            # an entered instance: its own tree is checked in object space (once per geometry root); what the top-level box
+            # has to contain is the world-space image of the instance's triangles
+            checked["instances"] += 1
+            rec = inst[payload]
+            root, first, count = (int(v) for v in rec[12:15].view(np.int32))
+            if root not in roots_done:
+                roots_done.add(root)
+                node_bounds(root, False)
+            m = rec[16:28].reshape(3, 4).astype(np.float64)
+            points = np.concatenate([verts[first:first + count].reshape(-1, 3).astype(np.float64), np.ones((3 * count, 1))], axis=1)
+            world = points @ m.T
+            return world.min(axis=0), world.max(axis=0)
+        first, count = payload & 0x0fffffff, ((payload >> 28) & 3) + 1
+        checked["leaves"] += 1
+        return slot_lo[first:first + count].min(axis=0).astype(np.float64), slot_hi[first:first + count].max(axis=0).astype(np.float64)
+
+    def node_bounds(index, top_level):
+        lo, hi, refs, unused = _decode_children(nodes[index])
+        checked["nodes"] += 1
+        total_lo, total_hi = np.full(3, np.inf), np.full(3, -np.inf)
+        assert (~unused).sum() >= 2, index
+        for k in range(4):
+            if unused[k]:
+                checked["unused"] += 1
+                assert np.all(lo[k] > hi[k]), (index, k)
+                continue
+            # the top level keeps being the top level below inner references (the world-space trees of flattened instances are spliced in)
+            b_lo, b_hi = subtree_bounds(int(refs[k]), top_level)
+            assert np.all(lo[k].astype(np.float64) <= b_lo) and np.all(b_hi <= hi[k].astype(np.float64)), (index, k, lo[k], hi[k], b_lo, b_hi)
+            total_lo, total_hi = np.minimum(total_lo, b_lo), np.maximum(total_hi, b_hi)  # of the GEOMETRY below: grids of different nodes do not nest
+        return total_lo, total_hi
+
+    node_bounds(int(info["root"]), True)
+    assert checked["nodes"] > 10 and checked["leaves"] > 10
+    if info["twoLevel"]:
+        assert checked["instances"] > 0

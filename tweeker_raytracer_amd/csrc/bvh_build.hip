@@ -442,25 +442,33 @@ void launchQuantizeWide(const BvhNode* wide, float4* out, int count, hipStream_t
 }
 
 // Top-of-tree cache (device_types.h TWK_NODE_CACHED): breadth-first from the root over the quantised wide nodes, the
-// first TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One thread: a few dozen nodes.
+// first TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One block: thread 0 walks the
+// queue, then one thread per slot copies its node and rewrites its references.
 __global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float4* __restrict__ top)
 {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int queue[TWK_TOP_NODES];
-  int n = 1;
-  queue[0] = root;
-  for (int i = 0; i < n; ++i)
+  __shared__ int queue[TWK_TOP_NODES];
+  __shared__ int count;
+  if (threadIdx.x == 0)
   {
-    const float4 refs = wideQ[4 * (size_t) queue[i] + 3];
-    const int r[4] = {__float_as_int(refs.x), __float_as_int(refs.y), __float_as_int(refs.z), __float_as_int(refs.w)};
-    const unsigned int qlx = __float_as_uint(wideQ[4 * (size_t) queue[i] + 1].z), qhx = __float_as_uint(wideQ[4 * (size_t) queue[i] + 2].y);
-    for (int k = 0; k < 4; ++k)
+    int n = 1;
+    queue[0] = root;
+    for (int i = 0; i < n; ++i)
     {
-      const bool unused = ((qlx >> (8 * k)) & 0xffu) > ((qhx >> (8 * k)) & 0xffu); // inverted box
-      if (!unused && r[k] >= 0 && r[k] != TWK_BVH_SENTINEL && n < TWK_TOP_NODES) queue[n++] = r[k];
+      const float4* w = wideQ + 4 * (size_t) queue[i];
+      const float4 refs = w[3];
+      const int r[4] = {__float_as_int(refs.x), __float_as_int(refs.y), __float_as_int(refs.z), __float_as_int(refs.w)};
+      const unsigned int qlx = __float_as_uint(w[1].z), qhx = __float_as_uint(w[2].y);
+      for (int k = 0; k < 4; ++k)
+      {
+        const bool unused = ((qlx >> (8 * k)) & 0xffu) > ((qhx >> (8 * k)) & 0xffu); // inverted box
+        if (!unused && r[k] >= 0 && r[k] != TWK_BVH_SENTINEL && n < TWK_TOP_NODES) queue[n++] = r[k];
+      }
     }
+    count = n;
   }
-  for (int i = 0; i < TWK_TOP_NODES; ++i)
+  __syncthreads();
+  const int n = count;
+  for (int i = threadIdx.x; i < TWK_TOP_NODES; i += blockDim.x)
   {
     float4* out = top + 4 * i;
     if (i >= n) { for (int k = 0; k < 4; ++k) out[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; } // slot never referenced

@@ -371,6 +371,11 @@ traceKernel(LaunchParams p, int depth)
         res.triangleSlot = closer ? (ts_) : res.triangleSlot;                                                                  \
         if (closer & ((state & ST_ANY_HIT) != 0u)) { pop = 0u; state = (state & ~ST_HAS_RAY) | ST_DONE; triLast = -1; }        \
       }
+      // (Postponed leaves — a lane keeps the reference of its first triangle leaf, goes on with the next node from its stack
+      // and parks only at its second leaf, so that this phase tests the leaves of more lanes at a time (speculative
+      // traversal, Aila & Laine 2009) — was built and measured on C2: lane occupancy of this phase 0.33 -> 0.42, of the
+      // node step 0.62 -> 0.64, but 3.4 % more node visits and 3 % more triangle tests before the postponed triangles can
+      // shorten the ray; kernel time -0.9 %, and the visit counts no longer equal the same-BVH host walker's. Not kept.)
       // (Handing a leaf's second triangle to an idle lane through the lane crossbar — 17 ds_bpermute + an LDS pairing table —
       // was built and measured: triangle-test lane occupancy 0.33 -> 0.59, kernel time +23 %. Not kept.)
       for (int ts = triFirst; ts <= triLast; ++ts)
