@@ -113,10 +113,41 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 #define TWK_SHADE_WAVES 4
 #endif
 
+// The streams of one queue slot, as loaded (the fetch is issued one block iteration ahead, see shadeKernel).
+struct ShadeInput
+{
+  float4 ro, rd, hit, throughputPdf;
+  uint2 seedFlags;
+  unsigned int pixel;
+  int instanceIndex;
+  bool inRange;
+};
+
+TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsigned int numRays, ShadeInput& in)
+{
+  in.inRange = slot < numRays;
+  if (in.inRange)
+  {
+    in.ro = p.rayOrg[q][slot];
+    in.rd = p.rayDir[q][slot];
+    in.pixel = p.rayPixel[q][slot];
+    in.hit = p.hitRecord[slot];
+    in.instanceIndex = p.hitInstance[slot];
+    in.throughputPdf = p.rayThroughput[q][slot];
+    in.seedFlags = p.raySeedFlags[q][slot];
+  }
+}
+
+// Block barrier that orders LDS only. __syncthreads() also drains the wave's outstanding global loads and stores
+// (s_waitcnt vmcnt(0)), which is exactly what the two barriers of the append must not do: see shadeKernel.
+TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(LaunchParams p, int depth)
 {
-  __shared__ unsigned int waveCount[2][TWK_SHADE_BLOCK / 64];
-  __shared__ unsigned int blockBase[2];
+  // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
+  // of iteration i + 1, so no third barrier per iteration is needed.
+  __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
+  __shared__ unsigned int blockBase[2][2];
 
   const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const int q = depth & 1, qn = q ^ 1;
@@ -127,46 +158,47 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
+  // The kernel is bound by its chain of dependent fetches, not by arithmetic, so the chain is kept
+  // short: the streams of the NEXT iteration's slot are requested between the two barriers of the append — they fly
+  // while the block waits for its returning atomic — and nothing waits for the appended records to be written.
+  ShadeInput in;
+  loadShadeInput(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, in);
+  unsigned int buffer = 0u;
+
   // block-uniform trip count: every thread reaches both barriers of every iteration
   for (unsigned int base = blockIdx.x * blockDim.x; base < numRays; base += gridDim.x * blockDim.x)
   {
-    const unsigned int slot = base + threadIdx.x;
     ShadeOutput out;
     out.alive = false; out.wantShadow = false;
-    unsigned int pixel = 0;
-    if (slot < numRays)
+    const unsigned int pixel = in.pixel;
+    if (in.inRange && in.rd.w >= 0.0f) // else: beyond the queue, or an inactive launch index (tile column beyond the image)
     {
-      const float4 ro = p.rayOrg[q][slot];
-      const float4 rd = p.rayDir[q][slot];
-      if (rd.w >= 0.0f) // else: inactive launch index (tile column beyond the image)
-      {
-        pixel = p.rayPixel[q][slot];
-        const float4 hit = p.hitRecord[slot];
-        const int instanceIndex = p.hitInstance[slot];
-        out.throughputPdf = p.rayThroughput[q][slot];
-        out.seedFlags     = p.raySeedFlags[q][slot];
-        shadePath(p, depth, pixel, ro, rd, hit, instanceIndex, out);
-        if (p.stats != nullptr) { if (instanceIndex < 0) ++statMiss; else ++statHit; }
-      }
+      out.throughputPdf = in.throughputPdf;
+      out.seedFlags     = in.seedFlags;
+      shadePath(p, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
+      if (p.stats != nullptr) { if (in.instanceIndex < 0) ++statMiss; else ++statHit; }
     }
 
     const unsigned long long shadowMask = __ballot(out.wantShadow);
     const unsigned long long nextMask   = __ballot(out.alive);
     if (lane == 0)
     {
-      waveCount[0][wave] = (unsigned int) __popcll(shadowMask);
-      waveCount[1][wave] = (unsigned int) __popcll(nextMask);
+      waveCount[buffer][0][wave] = (unsigned int) __popcll(shadowMask);
+      waveCount[buffer][1][wave] = (unsigned int) __popcll(nextMask);
     }
-    __syncthreads();
+    ldsBarrier();
+    // (hipcc still waits for part of these right here — it copies one component of the hit record to another register
+    // behind the loads; pinning the record at its first use makes that worse, every component then gets such a copy)
+    loadShadeInput(p, q, base + gridDim.x * blockDim.x + threadIdx.x, numRays, in);
     if (threadIdx.x < 2)
     {
       unsigned int total = 0;
-      for (unsigned int w = 0; w < TWK_SHADE_BLOCK / 64; ++w) total += waveCount[threadIdx.x][w];
-      blockBase[threadIdx.x] = (total != 0u) ? atomicAdd((threadIdx.x == 0) ? shadowCount : nextCount, total) : 0u;
+      for (unsigned int w = 0; w < TWK_SHADE_BLOCK / 64; ++w) total += waveCount[buffer][threadIdx.x][w];
+      blockBase[buffer][threadIdx.x] = (total != 0u) ? atomicAdd((threadIdx.x == 0) ? shadowCount : nextCount, total) : 0u;
     }
-    __syncthreads();
-    unsigned int shadowOffset = blockBase[0], nextOffset = blockBase[1];
-    for (unsigned int w = 0; w < wave; ++w) { shadowOffset += waveCount[0][w]; nextOffset += waveCount[1][w]; }
+    ldsBarrier();
+    unsigned int shadowOffset = blockBase[buffer][0], nextOffset = blockBase[buffer][1];
+    for (unsigned int w = 0; w < wave; ++w) { shadowOffset += waveCount[buffer][0][w]; nextOffset += waveCount[buffer][1][w]; }
 
     if (out.wantShadow)
     {
@@ -185,7 +217,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(
       p.rayThroughput[qn][n] = out.throughputPdf;
       p.raySeedFlags[qn][n]  = out.seedFlags;
     }
-    __syncthreads(); // waveCount / blockBase are rewritten by the next iteration
+    buffer ^= 1u;
   }
 
   if (p.stats != nullptr)

@@ -80,7 +80,7 @@ TWK_D void woopPermute(const WoopPermutation& w, const V3& v, float& vx, float& 
   vz = w.zIsX ? v.x : (w.zIsY ? v.y : v.z);
 }
 
-// The paper (and the oracle, oracle/orc_trace.h) exchanges kx and ky when d[kz] < 0 to keep the winding of the sheared
+// The paper (and the CPU restatement the parity tests compare with) exchanges kx and ky when d[kz] < 0 to keep the winding of the sheared
 // triangle. Nothing here culls by winding, and the exchange changes no result bit: with x and y exchanged every edge
 // function is the exact negation (U = Cx*By - Cy*Bx becomes Cy*Bx - Cx*By, also in the double-precision fallback), so
 // det and T change sign together and t = T / det, beta = V / det, gamma = W / det and every sign test come out the
