@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define TWK_ABI_VERSION 2
+/* 3: TwkLaunchStats grew by waveCycles[6] (twk_stats_get writes sizeof(TwkLaunchStats) bytes) and
+ * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
+#define TWK_ABI_VERSION 3
 
 typedef enum TwkResult
 {

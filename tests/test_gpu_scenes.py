@@ -580,3 +580,28 @@ def test_quantised_boxes_contain_everything_below_them(twk, scene_file):
     assert checked["nodes"] > 10 and checked["leaves"] > 10
     if info["twoLevel"]:
         assert checked["instances"] > 0
+
+
+@pytest.mark.gpu
+def test_wave_time_profile_of_the_traversal_kernel(twk):
+    """TwkLaunchStats.waveCycles: shader-clock time of the waves of the persistent traversal kernel per phase of its outer
+    loop, filled by the counting variant only. The phases partition the loop: they add up to (nearly) the whole-kernel
+    figure, every phase that must run on a scene with hits has time in it, and nothing is recorded with stats off."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (160, 90))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    dev.render(0)
+    dev.synchronizeStream()
+    assert all(v == 0 for v in dev.statsGet(reset=True)["waveCycles"])
+    dev.statsEnable(True)
+    dev.statsGet(reset=True)
+    for it in range(1, 5):
+        dev.render(it)
+    dev.synchronizeStream()
+    st = dev.statsGet(reset=True)
+    refill, node, leaf, tri, write, total = st["waveCycles"]
+    assert min(refill, node, tri, write) > 0 and total > 0
+    assert 0.6 * total <= refill + node + leaf + tri + write <= total  # the rest: the top-of-tree cache fill, idle turns of the refill, the loop exits
+    assert node > tri  # 7.6 node steps against 3 triangle tests per ray
+    assert st["nodeWaveSteps"] > 0 and st["nodesVisited"] <= 64 * st["nodeWaveSteps"]
+    dev.close()

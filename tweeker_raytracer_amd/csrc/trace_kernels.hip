@@ -466,6 +466,7 @@ traceKernel(LaunchParams p, int depth)
 
   if (COUNT)
   {
+    const unsigned long long kernelEnd = __builtin_readcyclecounter(); // before the counters' own atomics, which queue up behind each other
     atomicAdd(&p.stats[0], (unsigned long long) closestCount);
     atomicAdd(&p.stats[1], (unsigned long long) shadowCount);
     atomicAdd(&p.stats[2], (unsigned long long) nodeCount);
@@ -479,7 +480,7 @@ traceKernel(LaunchParams p, int depth)
     if (lane == 0)
     {
       for (int k = 0; k < 5; ++k) atomicAdd(&p.stats[18 + k], phaseCycles[k]);
-      atomicAdd(&p.stats[23], (unsigned long long) __builtin_readcyclecounter() - kernelStart);
+      atomicAdd(&p.stats[23], kernelEnd - kernelStart);
     }
   }
 #undef TWK_WAVE_STEP
