@@ -116,9 +116,12 @@ struct __attribute__((aligned(16))) BvhNode
 //   [2] qlo.z, qhi.x, qhi.y, qhi.z       child box = origin + q * cell, rounded outwards (lo down, hi up)
 //   [3] the four child references; an unused entry has the inverted box lo = 255, hi = 0 (its near planes lie behind
 //       its far planes for every ray) and repeats the first child's reference
-// Why 64 instead of the 128 bytes of full-precision boxes: a CU's vector memory path takes ONE divergent 16-byte lane
-// address per clock (tools/gather_probe2.hip) and the traversal is bound by it, not by arithmetic — the boxes only cull,
-// so precision can be traded for loads; the grid is 1/254 of the node's extent per axis, a few per cent more node visits.
+// Why 64 instead of the 128 bytes of full-precision boxes: half the lane loads per visit (a CU's vector memory path takes
+// ONE divergent 16-byte lane address per clock, tools/gather_probe2.hip) and half the node array (scenes of millions of
+// triangles are not cache-resident), and — what decides it on the cache-resident scenes, where the kernel is bound by
+// vector-instruction issue — the four children of a plane family share a word, so near and far planes are picked by the
+// ray's sign for all four at once (trace_kernels.hip). The boxes only cull, so their precision is free to trade: the grid
+// is 1/254 of the node's extent per axis, 1 % more node visits and 10 % more triangle tests on C2.
 
 // Top-of-tree cache of the persistent trace kernel: the first TWK_TOP_NODES wide nodes in breadth-first order from the
 // root (every ray visits them) are copied into LDS by each block. A reference TWK_NODE_CACHED | slot names a cached

@@ -217,9 +217,7 @@ traceKernel(LaunchParams p, int depth)
       {
         // one WIDE node = the four grandchildren of binary node `node` (two levels of the binary tree per round of
         // loads), 64 bytes: child boxes as 8-bit grid coordinates of the node's own box (device_types.h "quantised wide
-        // node") — FOUR 16-byte lane loads instead of eight; the CU's vector memory path takes one divergent lane
-        // address per clock and this kernel is bound by it (doubling the loads of the uncached nodes: +57 % time, 64
-        // more VALU instructions per step: +6 %).
+        // node") — four 16-byte lane loads instead of eight.
         float4 n0, n1, n2, n3;
         // hipcc merges the two branches into ONE set of flat_load instructions on a selected generic pointer, and that is the
         // faster form: forcing ds_read for the cached lanes and global_load for the others (empty asm pins in
