@@ -223,6 +223,7 @@ static void refreshParams(TwkDevice dev)
   p.twoLevel = dev->twoLevel ? 1 : 0;
   p.numInstances = (int) dev->instances.size();
   p.numLights = (int) dev->lights.size();
+  p.numMaterials = (int) dev->materials.size();
   p.miss = dev->miss;
   p.hasCutout = 0;
   for (const DevMaterial& m : dev->materials) if (m.textureCutout != 0) p.hasCutout = 1;

@@ -157,6 +157,7 @@ struct LaunchParams
   int   twoLevel;       // 0: every instance is flattened — the BVH is one world-space tree (top level + spliced instance trees) and no kernel ever enters an instance
   int   numInstances;
   int   numLights;
+  int   numMaterials;   // (the launch parameters are read with scalar loads: their layout shows in the kernels' code)
   int   miss;
   int   hasCutout;      // some material has cutout opacity: trace kernels run the stochastic any-hit candidate loop
   unsigned int envWidth, envHeight;
