@@ -213,7 +213,8 @@ traceKernel(LaunchParams p, int depth)
       // straight-line predicated code (nested LDS/HBM stack selects compiled to ~70 scalar branch instructions
       // per node). A lane whose stack would overflow abandons this traversal and re-traces its ray with the
       // spilling traverse() (cold path, not taken on the LBVHs of the shipped scenes).
-      while ((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
+      // (a lane without a ray holds node = TWK_BVH_SENTINEL: one comparison decides who steps)
+      while ((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
         // one WIDE node = the four grandchildren of binary node `node` (two levels of the binary tree per round of
         // loads), 64 bytes: child boxes as 8-bit grid coordinates of the node's own box (device_types.h "quantised wide
@@ -288,10 +289,10 @@ traceKernel(LaunchParams p, int depth)
           node = ldsStack[sp * stride];
         }
         if (overflow) state |= ST_RETRACE;
-        if (stop | overflow) state = (state & ~ST_HAS_RAY) | ST_DONE;
+        if (stop | overflow) { state = (state & ~ST_HAS_RAY) | ST_DONE; node = TWK_BVH_SENTINEL; }
         // Leave the node loop once most lanes are parked at a leaf: the stragglers resume in the next round
         // together with the lanes that come back from their leaf, instead of running at a few lanes per wave.
-        if (__popcll(__ballot((state & ST_HAS_RAY) && (unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_DEN < roundActive * TWK_TRACE_NODE_NUM) break;
+        if (__popcll(__ballot((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)) * TWK_TRACE_NODE_DEN < roundActive * TWK_TRACE_NODE_NUM) break;
       }
 
       TWK_PHASE_END(1)
@@ -456,6 +457,7 @@ traceKernel(LaunchParams p, int depth)
       }
 
       TWK_PHASE_END(4)
+      if (!(state & ST_HAS_RAY)) node = TWK_BVH_SENTINEL; // what the node loop's condition relies on
       const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
       if (active == 0ull) break;
       if (!exhausted && __popcll(active) < min(TWK_TRACE_REFILL, (int) ticketSize)) break;
