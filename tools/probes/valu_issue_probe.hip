@@ -21,6 +21,7 @@ template<int OP> __global__ void __launch_bounds__(256) probe(float* out, int it
     if (OP == 6) asm volatile(R8("v_pk_mul_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2\n") : "+v"(*(double*) &a), "+v"(*(double*) &c) : "v"(*(double*) &e));
     if (OP == 7) asm volatile(R8("v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %5, %1, vcc\n v_cmp_lt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %5, %3, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc");
     if (OP == 8) asm volatile(R8("v_add_u32 %0, %4, %0\n v_lshl_or_b32 %1, %1, 3, %5\n v_and_b32 %2, %4, %2\n v_add_u32 %3, %5, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f));
+    if (OP == 10) asm volatile(R8("v_fma_mix_f32 %0, %4, %5, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %5, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(u), "v"(f));
     if (OP == 9) asm volatile(R8("v_fma_f32 %0, %4, %5, %0\n v_min_f32 %1, %0, %1\n v_max_f32 %2, %1, %2\n v_cndmask_b32 %3, %2, %3, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc"); // dependent chain
   }
   if (a + b + c + d == 12345.678f) out[0] = a;
@@ -47,7 +48,7 @@ int main()
     run<0>("v_fma_f32", w, cus, dOut); run<1>("v_min/max_f32", w, cus, dOut); run<2>("v_cndmask_b32 (vcc)", w, cus, dOut);
     run<3>("v_cmp_lt_f32 -> vcc", w, cus, dOut); run<4>("v_cvt_f32_ubyteN", w, cus, dOut); run<5>("v_max3/min3_f32", w, cus, dOut);
     run<6>("v_pk_mul_f32", w, cus, dOut); run<7>("v_cmp + v_cndmask pairs", w, cus, dOut); run<8>("int add/lshl_or/and", w, cus, dOut);
-    run<9>("dependent fma>min>max>cndmask", w, cus, dOut);
+    run<9>("dependent fma>min>max>cndmask", w, cus, dOut); run<10>("v_fma_mix_f32 (f16 src0)", w, cus, dOut);
   }
   return 0;
 }
