@@ -208,7 +208,7 @@ struct LaunchParams
 
 // Counter block layout (unsigned int each), zeroed once per launch.
 // per depth d (0..maxDepth): [d*4+0] rays in queue d, [d*4+1] shadow rays emitted by shade d,
-// [d*4+2] trace work ticket of trace launch d, [d*4+3] rays of trace launch d that overflowed the LDS stack
+// [d*4+2] unused since the trace kernel deals its queue without a counter, [d*4+3] rays of trace launch d that overflowed the LDS stack
 #define TWK_COUNTERS_PER_DEPTH 4
 #define TWK_MAX_DEPTH 64
 
@@ -226,6 +226,8 @@ struct LaunchParams
 #ifndef TWK_SHADE_BLOCK
 #define TWK_SHADE_BLOCK       256  // threads per shadeKernel block: queue appends are aggregated per block. Measured (ms/step of shade): 128 → 0.48 (atomics), 256 → 0.33, 512 → 0.34 (waves wait at the block's barriers for its slowest wave), 1024 → 0.37
 #endif
-#define TWK_TRACE_TICKET      64   // queue slots per wave ticket (coarser tickets starve the chip: a launch holds only ~18 groups per wave)
+#ifndef TWK_TRACE_CHUNK
+#define TWK_TRACE_CHUNK       256  // queue slots per chunk of the persistent trace kernel's interleaved assignment (trace_kernels.hip)
+#endif
 
 } // namespace twk

@@ -93,7 +93,6 @@ traceKernel(LaunchParams p, int depth)
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const unsigned int numShadow  = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + 1] : 0u;
   const unsigned int total = numClosest + numShadow;
-  unsigned int* ticket = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 2];
 
   const int q = depth & 1;
   const unsigned int lane = threadIdx.x & 63u;
@@ -108,25 +107,23 @@ traceKernel(LaunchParams p, int depth)
   const unsigned long long kernelStart = phaseMark;
 #define TWK_PHASE_END(k) if (COUNT) { const unsigned long long now_ = __builtin_readcyclecounter(); phaseCycles[k] += now_ - phaseMark; phaseMark = now_; }
 
-  // Wave-uniform pool of queue slots. Most of the queue is handed out statically: wave w owns the contiguous range
-  // [w * S, (w + 1) * S) with S = 3/4 of its fair share (a multiple of 64), the last quarter is dealt dynamically in
-  // tickets of 64 from one atomic counter for load balance. Short queues (deep bounces) are spread over all waves
-  // in one static ticket of 16..64 rays and touch no atomic at all. Why: 6144 waves hitting one counter word cost
-  // ~100 us per EMPTY launch, and one word sustains only ~90 returning atomics/us (MI355X_MICROARCH "dequeue").
+  // Wave-uniform pool of queue slots, dealt WITHOUT any counter: the queue is cut into chunks and chunk c belongs to
+  // wave c mod numWaves, so every wave samples the whole queue (rays of one image region cost alike, and regions differ:
+  // sky against geometry) and the waves finish together. Chunks are TWK_TRACE_CHUNK rays; a short queue (deep bounces,
+  // or one iteration per pass) is spread over all waves in one chunk of 16.. rays each. History: tickets of 64 from one
+  // atomic counter for everything cost ~100 us per EMPTY launch (6144 waves on one word, which sustains ~90 returning
+  // atomics/us, MI355X_MICROARCH "dequeue"); a static contiguous 3/4 of each wave's share plus tickets for the rest
+  // was round 1's answer; measured in round 2 on C2 (ms/step): static share 1/2 0.890, 3/4 0.736, 7/8 0.666, 31/32 0.626,
+  // all static 0.643 — every ticket holds its whole wave for an atomic round trip — and interleaved chunks of
+  // 64 / 128 / 256 / 512 / 1024: 0.652 / 0.641 / 0.631 / 0.628 / 0.636, with the scenes that have sky 5-13 % faster
+  // than under any contiguous split (C3 3 310 -> 3 780, C4 geometry 3 530 -> 3 850 Msamples/s).
   const unsigned int numWaves = gridDim.x * (TWK_TRACE_BLOCK / 64);
   const unsigned int waveId   = blockIdx.x * (TWK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
-  unsigned int staticShare = ((total / numWaves) * 3u / 4u) & ~63u;
-  unsigned int ticketSize = 64u;
-  if (staticShare < 64u)
-  {
-    ticketSize = (total + numWaves - 1u) / numWaves;
-    ticketSize = min(64u, max(16u, (ticketSize + 15u) & ~15u));
-    staticShare = ticketSize;
-  }
-  const unsigned int staticEnd = numWaves * staticShare; // slots handed out without the counter
-  unsigned int poolBase = waveId * staticShare;
-  unsigned int poolCount = (poolBase < total) ? min(staticShare, total - poolBase) : 0u;
-  if (poolCount == 0u && staticEnd >= total) return; // nothing for this wave: no ray, no atomic
+  unsigned int ticketSize = TWK_TRACE_CHUNK;
+  if (total < numWaves * ticketSize) ticketSize = min((unsigned int) TWK_TRACE_CHUNK, max(16u, ((total + numWaves - 1u) / numWaves + 15u) & ~15u));
+  unsigned int nextChunk = waveId * ticketSize;
+  if (nextChunk >= total) return; // nothing for this wave
+  unsigned int poolBase = 0u, poolCount = 0u;
   bool exhausted = false;
 
   // per-lane ray state
@@ -169,15 +166,8 @@ traceKernel(LaunchParams p, int depth)
       {
         if (poolCount == 0u)
         {
-          if (staticEnd >= total) exhausted = true; // everything was handed out statically
-          else
-          {
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(ticket, (unsigned int) TWK_TRACE_TICKET);
-            base = __builtin_amdgcn_readfirstlane(base) + staticEnd;
-            if (base >= total) exhausted = true;
-            else { poolBase = base; poolCount = min((unsigned int) TWK_TRACE_TICKET, total - base); }
-          }
+          if (nextChunk >= total) exhausted = true;
+          else { poolBase = nextChunk; poolCount = min(ticketSize, total - nextChunk); nextChunk += numWaves * ticketSize; }
         }
         if (poolCount != 0u)
         {
@@ -201,7 +191,7 @@ traceKernel(LaunchParams p, int depth)
       if (__ballot((state & ST_HAS_RAY) != 0u) == 0ull)
       {
         if (exhausted) break;
-        continue; // pool was empty and the new ticket arrives next round
+        continue; // the pool was empty: the next chunk was taken just now
       }
     }
     TWK_PHASE_END(0)
