@@ -266,7 +266,7 @@ def main():
         gather_gbps = lane_loads * 16 / trace_s / 1.0e9
         # HBM-side bytes come from rocprofv3 --pmc passes (tools/pmc_collect.sh), which cannot run inside this process:
         # carried from the committed summary ONLY when it was taken on this very configuration, else null
-        valu_busy = None
+        valu_busy, valu_extra = None, {}
         traffic, traffic_note = None, "no PMC summary for this configuration (tools/pmc_collect.sh + tools/pmc_traffic.py write profiles/r02_trace_hbm_traffic.json)"
         pmc_path = os.path.join(ROOT, "profiles", "r02_trace_hbm_traffic.json")
         if os.path.exists(pmc_path):
@@ -278,6 +278,8 @@ def main():
                 if same:
                     traffic = pmc.get("hbm_bytes_per_launch")
                     valu_busy = pmc.get("valu_issue_utilisation")
+                    valu_extra = {"simd_clocks_per_vector_instruction_pmc": pmc.get("simd_clocks_per_vector_instruction"),
+                                  "valu_lane_utilisation_pmc": pmc.get("valu_lane_utilisation")}
                     traffic_note = f"carried from {os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this kernel, same steps / batch / resolution); not measured in this run"
                 else:
                     traffic_note = f"{os.path.basename(pmc_path)} was taken at steps {pmc.get('steps')}, batch {pmc.get('batch_depth')}, {pmc.get('resolution')}: not this run's launch size, so not reported"
@@ -289,6 +291,7 @@ def main():
             "lane_loads_vs_gather_ceiling": (lane_loads / trace_s / 1.0e9) / gather_peak,
             "valu_issue_utilisation_pmc": valu_busy,  # carried with `traffic` from the same PMC passes: not a memory roofline, but what bounds the kernel now
         }
+        fractions.update(valu_extra)  # one vector instruction per ~4 SIMD clocks = back to back for this instruction mix; lanes active per instruction
         # The scene (19 MB) lives in L2 / Infinity Cache: the algorithmic bytes are cache-level throughput and may exceed
         # what HBM could stream. The memory-side ceiling that does apply is the divergent-gather rate of the vector
         # memory path (one lane address per clock and CU), so that is the roofline reported; all three are in `fractions`.
