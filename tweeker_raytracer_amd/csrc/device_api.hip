@@ -479,7 +479,10 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
 
   const int traceGrid = traceGridBlocks(dev);
   int shadeGrid = (p.numPaths + TWK_SHADE_BLOCK - 1) / TWK_SHADE_BLOCK;
-  if (shadeGrid > dev->numCUs * (2048 / TWK_SHADE_BLOCK)) shadeGrid = dev->numCUs * (2048 / TWK_SHADE_BLOCK); // two rounds of resident blocks
+  // Many more blocks than are resident at once (4 per CU): a block that has finished its windows makes room for the next,
+  // which evens out what the blocks' windows cost. Measured on C2 (shade ms/step): 4 / 8 / 16 / 64 / 256 / 2048 blocks per
+  // CU = 0.310 / 0.309 / 0.305 / 0.294 / 0.290 / 0.298.
+  if (shadeGrid > dev->numCUs * TWK_SHADE_BLOCKS_PER_CU) shadeGrid = dev->numCUs * TWK_SHADE_BLOCKS_PER_CU;
 
   // Bounces [0, wavefrontDepth) run as per-depth trace/shade launches over compacted queues; the remaining bounces
   // of every surviving path run inside one persistent tail kernel (tail_kernel.hip).

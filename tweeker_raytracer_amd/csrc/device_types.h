@@ -208,7 +208,7 @@ struct LaunchParams
 
 // Counter block layout (unsigned int each), zeroed once per launch.
 // per depth d (0..maxDepth): [d*4+0] rays in queue d, [d*4+1] shadow rays emitted by shade d,
-// [d*4+2] unused since the trace kernel deals its queue without a counter, [d*4+3] rays of trace launch d that overflowed the LDS stack
+// [d*4+2] chunk tickets of trace launch d (second half of a long queue), [d*4+3] rays of trace launch d that overflowed the LDS stack
 #define TWK_COUNTERS_PER_DEPTH 4
 #define TWK_MAX_DEPTH 64
 
@@ -223,11 +223,12 @@ struct LaunchParams
 #endif
 #define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
 #define TWK_TRACE_BLOCK       256
+#define TWK_SHADE_BLOCKS_PER_CU 128 // grid of shadeKernel = numCUs x this at most (device_api.hip)
 #ifndef TWK_SHADE_BLOCK
 #define TWK_SHADE_BLOCK       256  // threads per shadeKernel block: queue appends are aggregated per block. Measured (ms/step of shade): 128 → 0.48 (atomics), 256 → 0.33, 512 → 0.34 (waves wait at the block's barriers for its slowest wave), 1024 → 0.37
 #endif
 #ifndef TWK_TRACE_CHUNK
-#define TWK_TRACE_CHUNK       256  // queue slots per chunk of the persistent trace kernel's interleaved assignment (trace_kernels.hip)
+#define TWK_TRACE_CHUNK       512  // queue slots per chunk of the persistent trace kernel's interleaved assignment (trace_kernels.hip)
 #endif
 
 } // namespace twk

@@ -70,6 +70,12 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 #define TWK_TRACE_REFILL 44
 #endif
 // The node loop of a round ends once fewer than NUM/DEN of the lanes that entered it are still at an inner node.
+#ifndef TWK_TRACE_TAIL_DEN
+#define TWK_TRACE_TAIL_DEN 2
+#endif
+#ifndef TWK_TRACE_TAIL_MIN
+#define TWK_TRACE_TAIL_MIN 2u // queues shorter than this many chunks per wave are dealt statically throughout
+#endif
 #ifndef TWK_TRACE_NODE_NUM
 #define TWK_TRACE_NODE_NUM 1
 #endif
@@ -107,16 +113,20 @@ traceKernel(LaunchParams p, int depth)
   const unsigned long long kernelStart = phaseMark;
 #define TWK_PHASE_END(k) if (COUNT) { const unsigned long long now_ = __builtin_readcyclecounter(); phaseCycles[k] += now_ - phaseMark; phaseMark = now_; }
 
-  // Wave-uniform pool of queue slots, dealt WITHOUT any counter: the queue is cut into chunks and chunk c belongs to
-  // wave c mod numWaves, so every wave samples the whole queue (rays of one image region cost alike, and regions differ:
-  // sky against geometry) and the waves finish together. Chunks are TWK_TRACE_CHUNK rays; a short queue (deep bounces,
-  // or one iteration per pass) is spread over all waves in one chunk of 16.. rays each. History: tickets of 64 from one
-  // atomic counter for everything cost ~100 us per EMPTY launch (6144 waves on one word, which sustains ~90 returning
-  // atomics/us, MI355X_MICROARCH "dequeue"); a static contiguous 3/4 of each wave's share plus tickets for the rest
-  // was round 1's answer; measured in round 2 on C2 (ms/step): static share 1/2 0.890, 3/4 0.736, 7/8 0.666, 31/32 0.626,
-  // all static 0.643 — every ticket holds its whole wave for an atomic round trip — and interleaved chunks of
-  // 64 / 128 / 256 / 512 / 1024: 0.652 / 0.641 / 0.631 / 0.628 / 0.636, with the scenes that have sky 5-13 % faster
-  // than under any contiguous split (C3 3 310 -> 3 780, C4 geometry 3 530 -> 3 850 Msamples/s).
+  // Wave-uniform pool of queue slots. The queue is cut into chunks of TWK_TRACE_CHUNK rays. The first half goes out
+  // statically and interleaved — chunk c belongs to wave c mod numWaves, so every wave samples the whole queue (rays of
+  // one image region cost alike, and regions differ: sky against geometry) — and touches no counter; the second half
+  // goes out in tickets of one chunk from the depth's counter word, so the waves that run ahead (the CUs do not all
+  // run alike) take what is left and all finish together. A short queue (deep bounces, or one iteration per pass) is
+  // spread over all waves statically, one chunk of 16.. rays each.
+  // History, C2, trace ms/step. Round 1: tickets of 64 from one counter for everything cost ~100 us per EMPTY launch
+  // (6144 waves on one word, which sustains ~90 returning atomics/us, MI355X_MICROARCH "dequeue"), hence a contiguous
+  // static 3/4 of each wave's share plus 64-ray tickets for the rest. Round 2: that static share at 1/2 0.890, 3/4 0.736
+  // (the default until then), 7/8 0.666, 31/32 0.626, all static 0.643 — every 64-ray ticket holds its wave for an atomic
+  // round trip; interleaved static chunks of 64 / 128 / 256 / 512 / 1024: 0.652 / 0.641 / 0.631 / 0.628 / 0.636, with the
+  // scenes that have sky 5-13 % faster than under any contiguous split; then tickets again, but of a whole chunk, for the
+  // last 1/64 .. all of the queue: 1/8 0.605, 1/4 0.582, 1/3 0.565, 1/2 0.545, all 0.568 (chunks of 256); chunks of 384 /
+  // 512 / 1024 at 1/2: 0.537 / 0.541 / 0.561.
   const unsigned int numWaves = gridDim.x * (TWK_TRACE_BLOCK / 64);
   const unsigned int waveId   = blockIdx.x * (TWK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
   unsigned int ticketSize = TWK_TRACE_CHUNK;
@@ -124,6 +134,12 @@ traceKernel(LaunchParams p, int depth)
   unsigned int nextChunk = waveId * ticketSize;
   if (nextChunk >= total) return; // nothing for this wave
   unsigned int poolBase = 0u, poolCount = 0u;
+#if TWK_TRACE_TAIL_DEN
+  unsigned int* ticket = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 2];
+  const unsigned int staticEnd = (total >= numWaves * ticketSize * TWK_TRACE_TAIL_MIN) ? ((total - total / TWK_TRACE_TAIL_DEN) / (numWaves * ticketSize)) * (numWaves * ticketSize) : total;
+#else
+  const unsigned int staticEnd = total;
+#endif
   bool exhausted = false;
 
   // per-lane ray state
@@ -166,8 +182,18 @@ traceKernel(LaunchParams p, int depth)
       {
         if (poolCount == 0u)
         {
-          if (nextChunk >= total) exhausted = true;
-          else { poolBase = nextChunk; poolCount = min(ticketSize, total - nextChunk); nextChunk += numWaves * ticketSize; }
+          if (nextChunk < staticEnd) { poolBase = nextChunk; poolCount = min(ticketSize, staticEnd - nextChunk); nextChunk += numWaves * ticketSize; }
+#if TWK_TRACE_TAIL_DEN
+          else if (staticEnd < total)
+          {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(ticket, ticketSize);
+            base = __builtin_amdgcn_readfirstlane(base) + staticEnd;
+            if (base >= total) exhausted = true;
+            else { poolBase = base; poolCount = min(ticketSize, total - base); }
+          }
+#endif
+          else exhausted = true;
         }
         if (poolCount != 0u)
         {
