@@ -126,7 +126,7 @@ traceKernel(LaunchParams p, int depth)
   // round trip; interleaved static chunks of 64 / 128 / 256 / 512 / 1024: 0.652 / 0.641 / 0.631 / 0.628 / 0.636, with the
   // scenes that have sky 5-13 % faster than under any contiguous split; then tickets again, but of a whole chunk, for the
   // last 1/64 .. all of the queue: 1/8 0.605, 1/4 0.582, 1/3 0.565, 1/2 0.545, all 0.568 (chunks of 256); chunks of 384 /
-  // 512 / 1024 at 1/2: 0.537 / 0.541 / 0.561.
+  // 512 / 1024 at 1/2: 0.537 / 0.541 / 0.561. Tickets that shrink to 64 / 128 rays over the last 1/8 .. 1/32 of the queue: no gain.
   const unsigned int numWaves = gridDim.x * (TWK_TRACE_BLOCK / 64);
   const unsigned int waveId   = blockIdx.x * (TWK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
   unsigned int ticketSize = TWK_TRACE_CHUNK;
