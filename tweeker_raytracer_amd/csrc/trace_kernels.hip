@@ -67,7 +67,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 //   * "while-while": all lanes first descend inner nodes together, then handle their leaf / instance entry /
 //     instance exit once, so a wave does not pay for three code paths per step.
 #ifndef TWK_TRACE_REFILL
-#define TWK_TRACE_REFILL 44
+#define TWK_TRACE_REFILL 52
 #endif
 // The node loop of a round ends once fewer than NUM/DEN of the lanes that entered it are still at an inner node.
 #ifndef TWK_TRACE_TAIL_DEN
