@@ -2,9 +2,9 @@
 // closesthit.cu:281-286 shadow rays; the traversal itself lives in closed libnvoptix.so.1).
 //
 // One persistent launch per bounce serves BOTH ray kinds: the closest-hit rays of bounce k+1 and the
-// any-hit shadow rays emitted by the shading of bounce k. A wave owns contiguous ranges of queue slots (mostly
-// dealt statically, the rest in tickets of 64 from one atomic counter) and hands them to its lanes as they fall
-// idle. Each lane walks the two-level BVH with its own stack — 4-ary wide nodes, TWK_TRACE_STACK_LDS entries in
+// any-hit shadow rays emitted by the shading of bounce k. A wave takes chunks of consecutive queue slots (the first
+// half of the queue interleaved statically, the second half in chunk-sized tickets) and hands them to its lanes as
+// they fall idle. Each lane walks the two-level BVH with its own stack — quantised 4-ary wide nodes, TWK_TRACE_STACK_LDS entries in
 // LDS laid out [entry][lane] (bank = lane, conflict free); a ray whose stack would overflow is handed to
 // traceOverflowKernel, whose single-ray traverse() over the binary nodes continues the stack in HBM. Instances are
 // entered by transforming the ray into object space (t is preserved), exactly what an OptiX IAS→GAS descent does;
@@ -59,7 +59,8 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // (depth & 1), slots [numClosest, numClosest + numShadow) the shadow rays emitted by shade(depth - 1).
 //
 // Structure (persistent threads with per-lane refill, after Aila & Laine 2009, re-tiled for 64-wide waves):
-//   * a wave owns a pool of consecutive queue slots: a static share first, then tickets of 64 from ONE atomic counter;
+//   * a wave owns a pool of consecutive queue slots, one chunk at a time: its interleaved static chunks first, then
+//     tickets of one chunk from the depth's counter word (see "Wave-uniform pool" below);
 //   * every lane carries one ray; when fewer than TWK_TRACE_REFILL lanes still hold a ray the wave leaves the
 //     traversal loop and hands fresh slots from its pool to the idle lanes (ballot + prefix popcount, no atomics) —
 //     ray lengths on this workload range from 3 to 100+ node visits, and without refill the wave idles on its
