@@ -605,3 +605,33 @@ def test_wave_time_profile_of_the_traversal_kernel(twk):
     assert node > tri  # 7.6 node steps against 3 triangle tests per ray
     assert st["nodeWaveSteps"] > 0 and st["nodesVisited"] <= 64 * st["nodeWaveSteps"]
     dev.close()
+
+
+@pytest.mark.gpu
+def test_queue_dealing_modes_at_full_size(twk, orc):
+    """The persistent traversal kernel deals its ray queue in three ways depending on the queue's length (one chunk per
+    wave for a short queue; interleaved static chunks; the second half in chunk-sized tickets once the queue is longer than
+    two chunks per wave — trace_kernels.hip "Wave-uniform pool"). At 1920x1080 a pass of 1 / 2 / 5 / 13 iterations starts with
+    2.1 / 4.1 / 10.4 / 27 M rays and shrinks through all three regimes as the bounces go on. Whatever the pass size, the
+    window of the frame equals the oracle's bit for bit after the same 13 iterations."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt")
+    assert list(app.info.resolution) == [1920, 1080]
+    x0, y0, x1, y1 = 1040, 40, 1104, 88
+    iters = 13
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    for it in range(iters):
+        ref.render(it, rect=(x0, y0, x1, y1), threads=8)
+    cpu = ref.getOutputBufferHost()[y0:y1, x0:x1]
+    ref.close()
+    assert cpu[..., :3].std() > 1e-3
+    for batch in (1, 2, 5, 13):
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        app.initDevice(dev)
+        dev.setLaunchBatch(batch)
+        for it in range(iters):
+            dev.render(it)
+        gpu = dev.getOutputBufferHost()[y0:y1, x0:x1]
+        mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+        assert mism == 0, f"batch {batch}: {mism} pixels differ"
+        dev.close()
