@@ -12,6 +12,10 @@ reference_helpers.npz — outputs of the REFERENCE's own code (oracle/_ref/libre
 oracle_cornell.npz — outputs of the ORACLE (brute-force traversal): C1 Cornell box 64x64 first-hit records and
   images at 1 and 2 spp, C2 (full BSDF set) 64x36 image at 2 spp. The reference has no golden images
   (SURVEY.md §4); these pin the oracle and the HIP path against regressions and against each other.
+oracle_cornell_objectspace.npz — the same arrays as oracle_cornell.npz made with the flatten policy (0, 0): every instance
+  intersected in OBJECT space with the ray taken through the inverse instance transform, which is what an OptiX
+  IAS -> GAS descent does (Device.cpp:1427-1489). Byte-identical to the file round 1 committed as oracle_cornell.npz
+  (commit a929824) before the flatten policy existed; the default-policy file differs from it by <= 8e-3 per channel.
 Fixtures are data only: inputs + expected outputs.
 """
 import hashlib
@@ -116,7 +120,7 @@ def reference_helpers():
     print("wrote reference_helpers.npz", len(out), "arrays")
 
 
-def oracle_cornell():
+def oracle_cornell(policy=None, name="oracle_cornell.npz"):
     import tweeker_raytracer_amd as twk
     from oracle import orc
     out = {}
@@ -126,6 +130,8 @@ def oracle_cornell():
     app.setResolution(64, 64)
     o = orc.Oracle(miss=app.info.miss)
     o.loadApplication(app)
+    if policy is not None:
+        o.setFlattenPolicy(*policy)
     o.setTraceMode(False)  # brute force: the definition
     o.captureFirstHits(True)
     o.render(0)
@@ -139,14 +145,17 @@ def oracle_cornell():
     app.setResolution(64, 36)
     o = orc.Oracle(miss=app.info.miss)
     o.loadApplication(app)
+    if policy is not None:
+        o.setFlattenPolicy(*policy)
     o.setTraceMode(False)
     for it in range(2):
         o.render(it)
     out["c2_64x36_spp2"] = o.getOutputBufferHost()
-    np.savez_compressed(os.path.join(HERE, "oracle_cornell.npz"), **out)
-    print("wrote oracle_cornell.npz")
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
 
 
 if __name__ == "__main__":
     reference_helpers()
     oracle_cornell()
+    oracle_cornell(policy=(0, 0), name="oracle_cornell_objectspace.npz")

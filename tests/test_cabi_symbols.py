@@ -50,3 +50,25 @@ def test_product_does_not_link_or_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "orc_" not in src and "liboracle" not in src and "from oracle" not in src and "import oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_every_entry_point_is_a_function_try_block():
+    """No C++ exception may cross the extern "C" boundary (the reference throws std::runtime_error, inc/CheckMacros.h:38-80;
+    a C caller cannot catch it): every definition of an `int twk_*(...)` entry point in the two files that hold them is a
+    function-try-block ending in TWK_CATCH("<its own name>"), except the few one-liners that cannot throw."""
+    cannot_throw = {"twk_abi_version", "twk_app_destroy"}  # return a constant / delete a pointer
+    seen = set()
+    for rel in ("csrc/device_api.hip", "csrc/host/host_cabi.cpp"):
+        text = open(os.path.join(ROOT, "tweeker_raytracer_amd", rel)).read()
+        for m in re.finditer(r"^int (twk_[a-z0-9_]+)\s*\(([^)]*)\)\s*\n(\S+)", text, flags=re.M):
+            name, following = m.group(1), m.group(3)
+            seen.add(name)
+            if name in cannot_throw:
+                continue
+            assert following == "try", f"{rel}: {name} is not a function-try-block"
+            assert f'TWK_CATCH("{name}")' in text, f"{rel}: {name} has no TWK_CATCH of its own"
+        for m in re.finditer(r"^int (twk_[a-z0-9_]+)\s*\([^)]*\)\s*\{", text, flags=re.M):  # one-line definitions
+            seen.add(m.group(1))
+            assert m.group(1) in cannot_throw, f"{rel}: {m.group(1)} is defined without a try block"
+    declared = set(_header_functions()) - {"twk_last_error"}
+    assert declared <= seen, declared - seen

@@ -1,13 +1,17 @@
 #!/bin/bash
 # PMC collection on the GPU box: separate rocprofv3 passes (SQ has 8 slots, TCC 4; FETCH_SIZE takes 3, WRITE_SIZE 2),
-# counters only combined with --kernel-trace. Output: gpurun_out/pmc/<pass>/..._counter_collection.csv
-# usage: tools/pmc_collect.sh <tag> [bench args]
+# counters only combined with --kernel-trace. Output: gpurun_out/<tag>/<pass>/..._counter_collection.csv
+# usage: tools/pmc_collect.sh <tag> [steps [warmup [further bench args]]]      (default 64 64: every launch the same size)
+# The driver's invocation is `--steps 20 --warmup 5`: tools/pmc_traffic.py then averages over the launches of the TIMED pass only.
 set -u
 TAG=${1:-pmc}; shift || true
+STEPS=${1:-64}; shift || true
+WARMUP=${1:-64}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-ARGS="--steps 64 --warmup 64 --no-cpu-baseline --no-roofline $*"
+ARGS="--steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-roofline $*"
+echo "$STEPS $WARMUP" > $OUT/steps_warmup.txt
 run() { # name counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"

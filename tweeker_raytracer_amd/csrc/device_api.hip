@@ -759,10 +759,14 @@ TWK_CATCH("twk_clear_scene")
 
 int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, size_t numAttributes,
                      const unsigned int* indices, size_t numIndices, int* idGeometry)
+try
 {
   int rc = activate(dev, "twk_add_geometry"); if (rc) return rc;
   if (!attributes || !indices || numAttributes == 0 || numIndices == 0 || (numIndices % 3) != 0)
     return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: need attributes and a non-empty multiple of three indices");
+  // a leaf reference holds a 28-bit triangle slot (device_types.h BvhNode): refuse here what twk_build could not address
+  if (numIndices / 3 >= ((size_t) 1 << 28) || numAttributes >= ((size_t) 1 << 32))
+    return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: more than 2^28 - 1 triangles (or 2^32 - 1 vertices) in one geometry");
   for (size_t i = 0; i < numIndices; ++i)
     if (indices[i] >= numAttributes) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_add_geometry: index out of range");
   GeometryHost g;
@@ -774,6 +778,7 @@ int twk_add_geometry(TwkDevice dev, const TwkTriangleAttributes* attributes, siz
   if (idGeometry) *idGeometry = (int) dev->geometries.size() - 1;
   return TWK_SUCCESS;
 }
+TWK_CATCH("twk_add_geometry")
 
 int twk_add_instance(TwkDevice dev, int idGeometry, const float transform[12], int idMaterial, int idLight, int* idInstance)
 try

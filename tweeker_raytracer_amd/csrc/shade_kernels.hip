@@ -371,18 +371,15 @@ __global__ void tonemapKernel(const float4* __restrict__ hdr, unsigned char* __r
   }
 }
 
-// Stream-copy peak (measurement only, twk_stream_peak_gbps): four 16-byte loads in flight per lane before the stores,
-// block-contiguous 4 KiB pieces.
+// Stream-copy peak (measurement only, twk_stream_peak_gbps): ONE float4 per thread, one block per 4 KiB piece, no loop.
+// tools/probes/stream_copy_probe.hip (profiles/r03a_stream_copy_probe.txt) on 1 GiB + 1 GiB / 4 GiB + 4 GiB buffers: this form
+// 6.18 / 6.24 TB/s = the guide's 6.29 for a float4 copy; round 2's form (4 pieces in flight per lane, 4096 blocks) 5.4-5.6;
+// grid-stride loops of 1..8 pieces at 8..64 blocks per CU 5.2-5.8, with non-temporal loads AND stores 5.8-6.1;
+// hipMemcpyAsync 4.8-5.1. (256 MiB buffers read 6.4-7.0: the Infinity Cache, not HBM.)
 __global__ void __launch_bounds__(256) streamCopyKernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
-  const size_t stride = (size_t) gridDim.x * blockDim.x * 4;
-  size_t i = (size_t) blockIdx.x * blockDim.x * 4 + threadIdx.x;
-  for (; i + 3 * 256 < n; i += stride)
-  {
-    const float4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
-    dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
-  }
-  for (; i < n; i += 256) dst[i] = src[i]; // tail of the last piece (n is a multiple of 256 in twk_stream_peak_gbps)
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
 
 // Divergent-gather ceiling of the chip (measurement only, twk_gather_peak): every lane walks its own pseudo-random
@@ -461,7 +458,7 @@ void launchTonemap(const float4* hdr, unsigned char* ldr, size_t numPixels, cons
 }
 void launchStreamCopy(const float4* src, float4* dst, size_t n, hipStream_t stream)
 {
-  hipLaunchKernelGGL(streamCopyKernel, dim3(4096), dim3(256), 0, stream, src, dst, n);
+  hipLaunchKernelGGL(streamCopyKernel, dim3((unsigned int) ((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
 }
 
 } // namespace twk
