@@ -233,6 +233,18 @@ def oracle_tonemap(rgba, tonemapper=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0
     return out
 
 
+def oracle_compositor(tiles, width, tileSize=(8, 8)):
+    """compositor.cu:38-64 on the CPU, one pass per source device: tiles float32 [deviceCount, height, launchWidth, 4]
+    -> image float32 [height, width, 4] (pixels no device owns keep -1)."""
+    lib = _load(ORACLE_PATH)
+    t = np.ascontiguousarray(tiles, dtype=np.float32)
+    n, h, lw, four = t.shape
+    assert four == 4
+    out = np.full((h, int(width), 4), -1.0, np.float32)
+    assert lib.orc_compositor(_f(t.reshape(-1)), _f(out.reshape(-1)), int(width), int(h), int(lw), int(n), int(tileSize[0]), int(tileSize[1])) == 0
+    return out
+
+
 class _Unit:
     """Scalar/vector unit taps shared by liboracle.so (orc_*) and libref_host.so (ref_*)."""
 

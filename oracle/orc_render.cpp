@@ -68,23 +68,71 @@ static inline float3 transformNormal(const float* m, float3 const& v)
   return r;
 }
 
-static inline float3 interpolateTexcoord(const HitContext& hc)
+// anyhit.cu:46-80 __anyhit__radiance_cutout, restated statement for statement: returns true where the program calls
+// optixIgnoreIntersection() (the candidate is skipped), false where it falls off its end (the candidate is accepted).
+// `seed` is thePrd->seed of the ray's payload.
+static inline bool anyhitRadianceCutout(const Oracle& o, const HitContext& hc, unsigned int& seed)
 {
-  const unsigned int* tri = &hc.geom->indices[3 * (size_t) hc.primitive];
-  const float alpha = 1.0f - hc.beta - hc.gamma;
-  return hc.geom->attributes[tri[0]].texcoord * alpha +
-         hc.geom->attributes[tri[1]].texcoord * hc.beta +
-         hc.geom->attributes[tri[2]].texcoord * hc.gamma;
+  const SystemData& sysData = o.sys;
+  const Geometry& g = *hc.geom;
+
+  MaterialDefinition const& material = sysData.materialDefinitions[hc.inst->material];
+
+  if (material.textureCutout != 0)
+  {
+    const unsigned int* tri = &g.indices[3 * (size_t) hc.primitive];
+
+    const float2 theBarycentrics = make_float2(hc.beta, hc.gamma);
+
+    const float  alpha = 1.0f - theBarycentrics.x - theBarycentrics.y;
+
+    const float3 texcoord = g.attributes[tri[0]].texcoord * alpha +
+                            g.attributes[tri[1]].texcoord * theBarycentrics.x +
+                            g.attributes[tri[2]].texcoord * theBarycentrics.y;
+
+    const float opacity = intensity(make_float3(tex2D(sysData.textures[1], texcoord.x, texcoord.y)));
+
+    if (opacity < 1.0f && opacity <= rng(seed))
+    {
+      return true;
+    }
+  }
+  return false;
 }
 
-// anyhit.cu:46-80 (radiance) and :94-132 (shadow): returns true when the candidate hit is ignored.
-static inline bool cutoutIgnores(const Oracle& o, const HitContext& hc, unsigned int& seed)
+// anyhit.cu:94-132 __anyhit__shadow_cutout: true = optixIgnoreIntersection(), false = FLAG_SHADOW + optixTerminateRay()
+// (the caller sets the flag). `seed` is the stream the shadow ray draws from (see "Cutout opacity" below).
+static inline bool anyhitShadowCutout(const Oracle& o, const HitContext& hc, unsigned int& seed)
 {
-  MaterialDefinition const& material = o.sys.materialDefinitions[hc.inst->material];
-  if (material.textureCutout == 0) return false;
-  const float3 texcoord = interpolateTexcoord(hc);
-  const float opacity = intensity(make_float3(tex2D(o.sys.textures[1], texcoord.x, texcoord.y)));
-  return (opacity < 1.0f && opacity <= rng(seed));
+  const SystemData& sysData = o.sys;
+  const Geometry& g = *hc.geom;
+
+  MaterialDefinition const& material = sysData.materialDefinitions[hc.inst->material];
+
+  float opacity = 1.0f;
+
+  if (material.textureCutout != 0)
+  {
+    const unsigned int* tri = &g.indices[3 * (size_t) hc.primitive];
+
+    const float2 theBarycentrics = make_float2(hc.beta, hc.gamma);
+    const float  alpha = 1.0f - theBarycentrics.x - theBarycentrics.y;
+
+    const float3 texcoord = g.attributes[tri[0]].texcoord * alpha +
+                            g.attributes[tri[1]].texcoord * theBarycentrics.x +
+                            g.attributes[tri[2]].texcoord * theBarycentrics.y;
+
+    opacity = intensity(make_float3(tex2D(sysData.textures[1], texcoord.x, texcoord.y)));
+  }
+
+  if (opacity < 1.0f && opacity <= rng(seed))
+  {
+    return true;
+  }
+  else
+  {
+    return false;
+  }
 }
 
 // Cutout opacity — what is pinned and what is a choice of this build (SURVEY.md §7 "RNG-stream fidelity"):
@@ -120,7 +168,7 @@ static Hit traceRadiance(Oracle& o, PerRayData* prd, const float3& org, const fl
     if (h.instance < 0) return h;
     const Instance& inst = o.scene.instances[h.instance];
     HitContext hc = { &inst, &o.scene.geometries[inst.geometry], h.primitive, h.beta, h.gamma, h.t };
-    if (!cutoutIgnores(o, hc, prd->seed)) return h;
+    if (!anyhitRadianceCutout(o, hc, prd->seed)) return h; // anyhit.cu:46-80
     lo = h.t; // continue strictly behind the ignored candidate
   }
 }
@@ -144,7 +192,7 @@ static bool traceShadow(Oracle& o, PerRayData* prd, const float3& org, const flo
     if (h.instance < 0) return false;
     const Instance& inst = o.scene.instances[h.instance];
     HitContext hc = { &inst, &o.scene.geometries[inst.geometry], h.primitive, h.beta, h.gamma, h.t };
-    if (!cutoutIgnores(o, hc, shadowSeed)) return true; // anyhit.cu:127-131
+    if (!anyhitShadowCutout(o, hc, shadowSeed)) return true; // anyhit.cu:94-132
     lo = h.t;
   }
 }
@@ -891,50 +939,111 @@ int orc_trace_rays(OrcHandle o, const float* rays, size_t numRays, int anyHit, f
 }
 
 // ---- tonemapper ------------------------------------------------------------------------------
-// Application::screenshot, tonemap branch (Application.cpp:2259-2297): the per-pixel loop, float3 helpers written out
-// (operator*, operator/ component-wise vector_math.h:509-529, lerp :547-550, clamp :148-151, powf :626-629).
+// Application::screenshot, tonemap branch (Application.cpp:2253-2297), the loop over idx restated statement for
+// statement (the reference's x / y loops are flattened into one index; float3 overloads: orc_vec.h).
 // tm = gamma, whitePoint, colorBalance[3], burnHighlights, crushBlacks, saturation, brightness (TonemapperGUI.h:34-43).
-int orc_tonemap(const float* tm, const float* rgba, size_t numPixels, unsigned char* rgb8)
+struct uchar3 { unsigned char x, y, z; };
+static inline uchar3 make_uchar3(unsigned char x, unsigned char y, unsigned char z) { return {x, y, z}; }
+struct TonemapperGUI { float gamma, whitePoint, colorBalance[3], burnHighlights, crushBlacks, saturation, brightness; };
+
+static void screenshotTonemap(const TonemapperGUI& m_tonemapperGUI, const float4* bufferHost, size_t numPixels, uchar3* dst)
 {
-  const float gamma = tm[0], whitePoint = tm[1];
-  const float balance[3] = {tm[2], tm[3], tm[4]};
-  const float invGamma       = 1.0f / gamma;                 // :2262
-  const float invWhitePoint  = tm[8] / whitePoint;           // :2264 brightness / whitePoint
-  const float burnHighlights = tm[5];
-  const float crushBlacks    = tm[6] + tm[6] + 1.0f;         // :2266
-  const float saturation     = tm[7];
-  for (size_t i = 0; i < numPixels; ++i)
+  const float  invGamma       = 1.0f / m_tonemapperGUI.gamma;
+  const float3 colorBalance   = make_float3(m_tonemapperGUI.colorBalance[0], m_tonemapperGUI.colorBalance[1], m_tonemapperGUI.colorBalance[2]);
+  const float  invWhitePoint  = m_tonemapperGUI.brightness / m_tonemapperGUI.whitePoint;
+  const float  burnHighlights = m_tonemapperGUI.burnHighlights;
+  const float  crushBlacks    = m_tonemapperGUI.crushBlacks + m_tonemapperGUI.crushBlacks + 1.0f;
+  const float  saturation     = m_tonemapperGUI.saturation;
+
+  for (size_t idx = 0; idx < numPixels; ++idx)
   {
-    float c[3];
-    for (int k = 0; k < 3; ++k)
-    {
-      float v = (invWhitePoint * balance[k]) * rgba[4 * i + k];           // :2275
-      v = v * ((v * burnHighlights + 1.0f) / (v + 1.0f));                 // :2276
-      c[k] = v;
-    }
-    float luminance = c[0] * 0.3f + c[1] * 0.59f + c[2] * 0.11f;         // :2278 dot()
-    for (int k = 0; k < 3; ++k)
-    {
-      c[k] = luminance + saturation * (c[k] - luminance);                 // :2279 lerp(make_float3(luminance), ldrColor, saturation)
-      c[k] = fmaxf(0.0f, c[k]);                                           // :2280
-    }
-    luminance = c[0] * 0.3f + c[1] * 0.59f + c[2] * 0.11f;               // :2282
+    float3 hdrColor = make_float3(bufferHost[idx]);
+    float3 ldrColor = invWhitePoint * colorBalance * hdrColor;
+    ldrColor       *= ((ldrColor * burnHighlights) + 1.0f) / (ldrColor + 1.0f);
+
+    float luminance = dot(ldrColor, make_float3(0.3f, 0.59f, 0.11f));
+    ldrColor = lerp(make_float3(luminance), ldrColor, saturation);
+    ldrColor = fmaxf3v(make_float3(0.0f), ldrColor);
+
+    luminance = dot(ldrColor, make_float3(0.3f, 0.59f, 0.11f));
     if (luminance < 1.0f)
     {
-      const float s = sqrtf(luminance);
-      for (int k = 0; k < 3; ++k)
-      {
-        const float crushed = pm_powf(c[k], crushBlacks);                 // :2285
-        c[k] = crushed + s * (c[k] - crushed);                            // :2286 lerp(crushed, ldrColor, sqrtf(luminance))
-        c[k] = fmaxf(0.0f, c[k]);                                         // :2287
-      }
+      const float3 crushed = powf3(ldrColor, crushBlacks);
+      ldrColor = lerp(crushed, ldrColor, sqrtf(luminance));
+      ldrColor = fmaxf3v(make_float3(0.0f), ldrColor);
     }
-    for (int k = 0; k < 3; ++k)
+    ldrColor = clamp3(powf3(ldrColor, invGamma), 0.0f, 1.0f);
+
+    dst[idx] = make_uchar3((unsigned char) (ldrColor.x * 255.0f),
+                           (unsigned char) (ldrColor.y * 255.0f),
+                           (unsigned char) (ldrColor.z * 255.0f));
+  }
+}
+
+int orc_tonemap(const float* tm, const float* rgba, size_t numPixels, unsigned char* rgb8)
+{
+  TonemapperGUI gui;
+  gui.gamma = tm[0]; gui.whitePoint = tm[1];
+  gui.colorBalance[0] = tm[2]; gui.colorBalance[1] = tm[3]; gui.colorBalance[2] = tm[4];
+  gui.burnHighlights = tm[5]; gui.crushBlacks = tm[6]; gui.saturation = tm[7]; gui.brightness = tm[8];
+  static_assert(sizeof(uchar3) == 3 && sizeof(float4) == 16, "packed pixels");
+  screenshotTonemap(gui, reinterpret_cast<const float4*>(rgba), numPixels, reinterpret_cast<uchar3*>(rgb8));
+  return 0;
+}
+
+// ---- compositor ------------------------------------------------------------------------------
+// compositor.cu:38-64, one launch index (xLaunch, yLaunch) of the kernel; compositor_data.h:34-48 for the arguments.
+struct CompositorData
+{
+  const float4* tileBuffer;
+  float4*       outputBuffer;
+  int2 resolution;
+  int2 tileSize;
+  int2 tileShift;
+  int  launchWidth;
+  int  deviceCount;
+  int  deviceIndex;
+};
+
+static void compositor(const CompositorData* args, const unsigned int xLaunch, const unsigned int yLaunch)
+{
+  if (yLaunch < (unsigned int) args->resolution.y)
+  {
+    const unsigned int xBlock = xLaunch >> args->tileShift.x;
+    const unsigned int yBlock = yLaunch >> args->tileShift.y;
+
+    const unsigned int xTile = xBlock * args->deviceCount + ((args->deviceIndex + yBlock) % args->deviceCount);
+
+    const unsigned int xPixel = xTile * args->tileSize.x + (xLaunch & (args->tileSize.x - 1));
+
+    if (xPixel < (unsigned int) args->resolution.x)
     {
-      const float g = pm_powf(c[k], invGamma);
-      const float ldr = fmaxf(0.0f, fminf(g, 1.0f));                      // :2289 clamp()
-      rgb8[3 * i + k] = (unsigned char) (ldr * 255.0f);                   // :2291-2293
+      const float4 *src = args->tileBuffer;
+      float4       *dst = args->outputBuffer;
+
+      dst[yLaunch * args->resolution.x + xPixel] = src[yLaunch * args->launchWidth + xLaunch];
     }
+  }
+}
+
+// tiles: [deviceCount][height][launchWidth] float4, the gathered tile buffers; output: [height][width] float4.
+// One compositor pass per source device, as DeviceMultiGPULocalCopy::compositor runs them (DeviceMultiGPULocalCopy.cpp:279-337).
+int orc_compositor(const float* tiles, float* output, int width, int height, int launchWidth, int deviceCount, int tileX, int tileY)
+{
+  for (int device = 0; device < deviceCount; ++device)
+  {
+    CompositorData args;
+    args.tileBuffer   = reinterpret_cast<const float4*>(tiles) + (size_t) device * height * launchWidth;
+    args.outputBuffer = reinterpret_cast<float4*>(output);
+    args.resolution   = {width, height};
+    args.tileSize     = {tileX, tileY};
+    args.tileShift    = calculateTileShift(args.tileSize);
+    args.launchWidth  = launchWidth;
+    args.deviceCount  = deviceCount;
+    args.deviceIndex  = device;
+    for (unsigned int y = 0; y < (unsigned int) height; ++y)
+      for (unsigned int x = 0; x < (unsigned int) launchWidth; ++x)
+        compositor(&args, x, y);
   }
   return 0;
 }

@@ -66,6 +66,13 @@ static inline float fmaxf3(const float3& a) { return fmaxf(fmaxf(a.x, a.y), a.z)
 static inline float3 expf3(const float3& v) { return {pm_expf(v.x), pm_expf(v.y), pm_expf(v.z)}; }
 
 static inline float clampf(float v, float lo, float hi) { return fmaxf(lo, fminf(v, hi)); } // vector_math.h:148-151
+// the float3 overloads the screenshot tonemapper uses (Application.cpp:2275-2289): vector_math.h:455-458 (float3 + float),
+// :526-529 (float3 / float3), :438-441 (fmaxf), :562-565 (clamp), :626-629 (powf, with the portable pm_powf)
+static inline float3 operator+(const float3& a, float b) { return {a.x + b, a.y + b, a.z + b}; }
+static inline float3 operator/(const float3& a, const float3& b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+static inline float3 fmaxf3v(const float3& a, const float3& b) { return {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+static inline float3 clamp3(const float3& v, float a, float b) { return {clampf(v.x, a, b), clampf(v.y, a, b), clampf(v.z, a, b)}; }
+static inline float3 powf3(const float3& v, float e) { return {pm_powf(v.x, e), pm_powf(v.y, e), pm_powf(v.z, e)}; }
 static inline int clampi(int v, int lo, int hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
 
 } // namespace orc

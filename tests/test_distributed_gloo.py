@@ -44,6 +44,7 @@ def _worker(rank, world, port, outdir):
                     px = twk.tile_column(x, y, (8, 8), world, d)  # compositor.cu:45-54
                     if px < RES[0]:
                         out[y, px] = tiles[d, y, x]
+        assert np.array_equal(out, orc.oracle_compositor(tiles, RES[0], (8, 8)))  # compositor.cu:38-64 restated in the oracle
         np.save(os.path.join(outdir, "composed.npy"), out)
     dist.barrier()
     dist.destroy_process_group()

@@ -189,7 +189,7 @@ def test_c5_tile_set_crop_parity(twk, orc):
     dev.close()
 
 
-def test_compositor_kernel(twk):
+def test_compositor_kernel(twk, orc):
     """twk_compositor scatters the gathered [N][H][launchWidth] tile sets into the W x H image like compositor.cu:38-64.
     Device buffers come straight from the HIP runtime the library itself links (ctypes), no torch involved."""
     import ctypes as C
@@ -223,6 +223,7 @@ def test_compositor_kernel(twk):
                 if px < w:
                     expect[y, px] = src[d, y, x]
     assert np.array_equal(got, expect) and (got >= 0).all()
+    assert np.array_equal(got, orc.oracle_compositor(src, w, (8, 8)))  # the oracle's statement-pinned restatement of compositor.cu
     dev.close()
 
 

@@ -304,3 +304,225 @@ def test_integrator_loop(texts):
     drop = {"const SystemData&sysData=o.sys;", "albedo=make_float3(0.0f);", "normal=make_float3(0.0f);", "prd.normal=make_float3(0.0f);"}
     orc = [s for s in orc if s not in drop]
     assert orc == ref, _diff(ref, orc)
+
+
+# =====================================================================================================================
+# Round 3: the programs round 2 left unpinned ("What's missing" 3): __raygen__path_tracer, distribute,
+# __anyhit__*, compositor, the Optix7Gui light block and denoiser AOV code, Texture::calculateSphericalCDF +
+# gaussianFilter, and the screenshot tonemap loop. Same method: statement lists must be EQUAL after the documented
+# renames and the one-to-one statement maps below; what is this build's own (tiled output index, seed by absolute pixel,
+# AOV additions to the rtigo3 programs) is named in the map, never silently dropped.
+# =====================================================================================================================
+REF7 = "/root/reference/apps/Optix7Gui/shaders"
+REF_SRC = "/root/reference/apps/rtigo3/src"
+
+CASTS = [(r"\(unsigned int\)\s*", ""), (r"reinterpret_cast<(?:const )?float4\s*\*>\(([^()]*)\)", r"\1")]  # benign on both sides
+
+
+def stmts(body, renames=(), extra_spelling=()):
+    for pat, rep in extra_spelling:
+        body = re.sub(pat, rep, body)
+    return statements(body, renames)
+
+
+def mapped(ref_statements, table):
+    out = []
+    for s in ref_statements:
+        if s in table:
+            rep = table[s]
+            if rep is not None:
+                for x in (rep if isinstance(rep, list) else [rep]):
+                    out.extend(_split_control(x))
+        else:
+            out.append(s)
+    return out
+
+
+def test_distribute(texts):
+    ref = stmts(function_body(texts["raygeneration.cu"], "distribute"), [(r"launchIndex\.x", "x"), (r"launchIndex\.y", "y")])
+    orc = stmts(function_body(texts["orc_render"], "distribute"))
+    assert orc == ref, _diff(ref, orc)
+
+
+def test_compositor():
+    ref_text = read(os.path.join(REF, "compositor.cu"))
+    ref = stmts(function_body(ref_text, "compositor"), extra_spelling=CASTS)
+    ref = mapped(ref, {  # the launch index comes from the caller's loops instead of blockIdx / threadIdx
+        "const unsigned int xLaunch=blockIdx.x*blockDim.x+threadIdx.x;": None,
+        "const unsigned int yLaunch=blockIdx.y*blockDim.y+threadIdx.y;": None,
+    })
+    orc = stmts(function_body(read(os.path.join(ROOT, "oracle", "orc_render.cpp")), "compositor"), extra_spelling=CASTS)
+    assert orc == ref, _diff(ref, orc)
+
+
+ANYHIT_RENAMES = REF_RENAMES + [
+    (r"attributes\[tri\.x\]", "g.attributes[tri[0]]"), (r"attributes\[tri\.y\]", "g.attributes[tri[1]]"), (r"attributes\[tri\.z\]", "g.attributes[tri[2]]"),
+    (r"thePrd->seed", "seed"), (r"theData->materialIndex", "hc.inst->material"),
+]
+ANYHIT_MAP = {
+    "GeometryInstanceData*theData=reinterpret_cast<GeometryInstanceData*>(optixGetSbtDataPointer());": ["const SystemData&sysData=o.sys;", "const Geometry&g=*hc.geom;"],
+    "const uint3*indices=reinterpret_cast<uint3*>(theData->indices);": None,
+    "const TriangleAttributes*attributes=reinterpret_cast<TriangleAttributes*>(theData->attributes);": None,
+    "const unsigned int thePrimitiveIndex=optixGetPrimitiveIndex();": None,
+    "const uint3 tri=indices[thePrimitiveIndex];": "const unsigned int*tri=&g.indices[3*hc.primitive];",
+    "const float2 theBarycentrics=optixGetTriangleBarycentrics();": "const float2 theBarycentrics=make_float2(hc.beta,hc.gamma);",
+    "PerRayData*thePrd=mergePointer(optixGetPayload_0(),optixGetPayload_1());": None,
+    "optixIgnoreIntersection();": "return true;",   # the candidate is skipped
+    "thePrd->flags|=FLAG_SHADOW;": None,              # set by the caller from the return value (closesthitRadiance: if(shadowed) ...)
+    "optixTerminateRay();": "return false;",          # the candidate is accepted and ends the shadow ray
+}
+
+
+def test_anyhit_programs(texts):
+    orc_text = texts["orc_render"]
+    ref = mapped(stmts(function_body(texts["anyhit.cu"], "__anyhit__radiance_cutout"), ANYHIT_RENAMES), ANYHIT_MAP)
+    orc = stmts(function_body(orc_text, "anyhitRadianceCutout"))
+    assert orc[-1] == "return false;"   # falling off the end of the program = the candidate is accepted
+    assert orc[:-1] == ref, _diff(ref, orc[:-1])
+    ref = mapped(stmts(function_body(texts["anyhit.cu"], "__anyhit__shadow_cutout"), ANYHIT_RENAMES), ANYHIT_MAP)
+    orc = stmts(function_body(orc_text, "anyhitShadowCutout"))
+    assert orc == ref, _diff(ref, orc)
+    # __anyhit__shadow (opaque materials): flag + terminate on the FIRST candidate = an any-hit query
+    ref = stmts(function_body(texts["anyhit.cu"], "__anyhit__shadow"))
+    assert ref == ["PerRayData*thePrd=mergePointer(optixGetPayload_0(),optixGetPayload_1());", "thePrd->flags|=FLAG_SHADOW;", "optixTerminateRay();"]
+    shadow = stmts(function_body(orc_text, "traceShadow"))
+    assert "return o.scene.trace(org,dir,tmin,tmax,true).instance>=0;" in shadow
+    # and the radiance / shadow loops call the two cutout programs per candidate, closest first
+    assert "if(!anyhitShadowCutout(o,hc,shadowSeed))" in shadow
+    assert "if(!anyhitRadianceCutout(o,hc,prd->seed))" in stmts(function_body(orc_text, "traceRadiance"))
+
+
+RAYGEN_RENAMES = REF_RENAMES + [(r"theLaunchIndex\.x", "lx"), (r"theLaunchIndex\.y", "ly"), (r"\bisnan\(", "std::isnan("), (r"\bbuffer\[index\]", "o.output[index]")]
+RAYGEN_MAP = {
+    "const uint2 theLaunchIndex=make_uint2(optixGetLaunchIndex());": "const SystemData&sysData=o.sys;",   # lx, ly are parameters
+    "unsigned int launchColumn=lx;": ["unsigned int launchColumn=lx;", "const bool tiled=(sysData.distribution&&1<sysData.deviceCount);"],
+    "if(sysData.distribution&&1<sysData.deviceCount)": "if(tiled)",
+    "launchColumn=distribute(theLaunchIndex);": "launchColumn=distribute(sysData,lx,ly);",
+    "PerRayData prd;": ["PerRayData prd;", "memset(&prd,0,sizeof(prd));"],
+    "const uint2 theLaunchDim=make_uint2(optixGetLaunchDimensions());": None,
+    # THE stated deviation: seed by absolute pixel for every device count; identical for one device
+    "const unsigned int seedIndex=theLaunchDim.x*ly+launchColumn*sysData.deviceCount+sysData.deviceIndex;": "const unsigned int seedIndex=sysData.resolution.x*ly+launchColumn;",
+    "const float2 screen=make_float2(sysData.resolution);": "const float2 screen=make_float2(float(sysData.resolution.x),float(sysData.resolution.y));",
+    "const float2 pixel=make_float2(launchColumn,ly);": "const float2 pixel=make_float2(float(launchColumn),float(ly));",
+    "optixDirectCall<void,const float2,const float2,const float2,float3&,float3&>(sysData.lensShader,screen,pixel,sample,prd.pos,prd.wi);": "callLens(sysData,sysData.lensShader,screen,pixel,sample,prd.pos,prd.wi);",
+    "float3 radiance=integrator(prd);": ["float3 albedo,normal;", "float3 radiance=integrator(o,prd,o.captureFirstHits?&o.firstHits[index]:nullptr,albedo,normal);", "rayTally().samples++;"],
+    "float4*buffer=sysData.outputBuffer;": None,   # (after the cast normalisation) the output lives in the Oracle object
+    # single buffer :229 `ly * resolution.x + launchColumn`; local copy :318 `theLaunchDim.x * ly + lx` — one expression here
+    "const unsigned int index=ly*sysData.resolution.x+launchColumn;": None,
+    "const float4 dst=o.output[index];": None,
+    "radiance=lerp(make_float3(dst),radiance,1.0f/float(sysData.iterationIndex+1));": ["const float t=1.0f/float(sysData.iterationIndex+1);", "const float4 dst=o.output[index];", "radiance=lerp(make_float3(dst),radiance,t);"],
+}
+
+
+def test_raygen_path_tracer(texts):
+    ref = mapped(stmts(function_body(texts["raygeneration.cu"], "__raygen__path_tracer"), RAYGEN_RENAMES, CASTS), RAYGEN_MAP)
+    body = function_body(texts["orc_render"], "raygenPathTracer")
+    body = re.sub(r"if \(o\.aov\)[^\n]*\n\s*\{.*?\n\s*\}\n", "", body, flags=re.S)   # Optix7Gui's AOV running means: test_optix7gui_*
+    orc = stmts(body, extra_spelling=CASTS)
+    index = "const unsigned int index=tiled?(ly*o.launchWidth+lx):(ly*sysData.resolution.x+launchColumn);"
+    assert index in orc, orc
+    orc.remove(index)                      # computed before the integrator call (first-hit capture needs it); see RAYGEN_MAP
+    assert orc == ref, _diff(ref, orc)
+
+
+def _read7(name):
+    global DEFINES
+    saved = dict(DEFINES)
+    DEFINES.update({"USE_DENOISER_ALBEDO": 1, "USE_DENOISER_NORMAL": 1, "USE_FP32_OUTPUT": 1})  # app_config.h:59-67; the normal AOV is built too
+    try:
+        return read(os.path.join(REF7, name))
+    finally:
+        DEFINES.clear()
+        DEFINES.update(saved)
+
+
+def _between(seq, first, last):
+    i = next(k for k, s in enumerate(seq) if s.startswith(first))
+    j = next(k for k, s in enumerate(seq) if k >= i and s.startswith(last))
+    return seq[i:j + 1]
+
+
+def test_optix7gui_light_block(texts):
+    """apps/Optix7Gui/shaders/closesthit.cu:189-226 vs the block closesthitRadiance runs under TWK_SHADERS_OPTIX7GUI."""
+    ren = REF_RENAMES + [(r"sysParameter", "sysData"), (r"theData->lightIndex", "hc.inst->light")]
+    ref = stmts(function_body(_read7("closesthit.cu"), "__closesthit__radiance"), ren)
+    ref = _between(ref, "if(0<=hc.inst->light)", "return;")
+    body = function_body(texts["orc_render"], "closesthitRadiance")
+    orc = _between(stmts(body), "if(0<=hc.inst->light&&o.shaderVariant==TWK_SHADERS_OPTIX7GUI)", "return;")
+    ref[0] = ref[0].replace("if(0<=hc.inst->light)", "if(0<=hc.inst->light&&o.shaderVariant==TWK_SHADERS_OPTIX7GUI)")
+    # FLAG_HIT: Optix7Gui sets it with FLAG_FRONTFACE at :172 for every hit; here it is only needed by the normal AOV, so it is set where the path ends
+    orc = [s.replace("(FLAG_HIT|FLAG_LIGHT|FLAG_TERMINATE)", "(FLAG_LIGHT|FLAG_TERMINATE)") for s in orc]
+    assert orc == ref, _diff(ref, orc)
+
+
+def test_optix7gui_aov_code(texts):
+    """Denoiser AOVs: albedo / normal capture in the integrator loop (apps/Optix7Gui/shaders/raygeneration.cu:125-164) and
+    their running means in the raygen program (:239-262)."""
+    ren = REF_RENAMES + [(r"sysParameter\.cameraU", "cam.U"), (r"sysParameter\.cameraV", "cam.V"), (r"sysParameter\.cameraW", "cam.W"), (r"sysParameter", "sysData"),
+                         (r"bufferRGBA\[index\]", "o.output[index]"), (r"bufferAlbedo\[index\]", "o.aovAlbedo[index]"), (r"bufferNormal\[index\]", "o.aovNormal[index]"),
+                         (r"\bisnan\(", "std::isnan(")]
+    ref = stmts(function_body(_read7("raygeneration.cu"), "__raygen__pathtracer"), ren)
+    integ = stmts(function_body(texts["orc_render"], "integrator"))
+    # capture block
+    r = _between(ref, "if(!(prd.flags&FLAG_ALBEDO)", "normal=make_float3(dot(prd.normal")
+    o = _between(integ, "if(!(prd.flags&FLAG_ALBEDO)", "normal=make_float3(dot(prd.normal")
+    r = mapped(r, {
+        # vector_math.h:562-565 clamp(float3, a, b) written out per component
+        "albedo=clamp(throughput*prd.albedo,0.0f,1.0f);": ["const float3 a=throughput*prd.albedo;", "albedo=make_float3(clampf(a.x,0.0f,1.0f),clampf(a.y,0.0f,1.0f),clampf(a.z,0.0f,1.0f));"],
+        # FLAG_HIT of Optix7Gui's closest hit (:172) = the radiance ray hit something
+        "if(depth==0&&(prd.flags&FLAG_HIT))": ["if(depth==0&&h.instance>=0)", "const CameraDefinition&cam=sysData.cameraDefinitions[0];"],
+    })
+    assert o == r, _diff(r, o)
+    # running means
+    r = _between(ref, "if(!(std::isnan(radiance.x)", "o.aovNormal[index]=make_float4(normal,0.0f);")
+    o = _between(stmts(function_body(texts["orc_render"], "raygenPathTracer")), "if(!(std::isnan(radiance.x)", "o.aovNormal[index]=make_float4(normal,0.0f);")
+    r = mapped(r, {
+        "const unsigned int index=theLaunchIndex.y*theLaunchDim.x+theLaunchIndex.x;": None,   # computed earlier (test_raygen_path_tracer)
+        "float4*bufferRGBA=reinterpret_cast<float4*>(sysData.outputBuffer);": None,
+        "float4*bufferAlbedo=reinterpret_cast<float4*>(sysData.albedoBuffer);": None,
+        "float4*bufferNormal=reinterpret_cast<float4*>(sysData.normalBuffer);": None,
+        "radiance=lerp(make_float3(o.output[index]),radiance,t);": ["const float4 dst=o.output[index];", "radiance=lerp(make_float3(dst),radiance,t);", "if(o.aov)"],
+        "o.output[index]=make_float4(radiance,1.0f);": ["o.output[index]=make_float4(radiance,1.0f);", "if(o.aov)"],
+    })
+    assert o == r, _diff(r, o)
+
+
+def test_spherical_cdf_and_gaussian_filter(texts):
+    """Texture::calculateSphericalCDF + gaussianFilter (apps/rtigo3/src/Texture.cpp:1499-1645): the one host piece the
+    reference-built helper cannot execute (Texture.cpp needs DevIL and the CUDA driver)."""
+    tex = read(os.path.join(REF_SRC, "Texture.cpp"))
+    orc_text = texts["orc_render"]
+    ref = stmts(function_body(tex, "gaussianFilter"))
+    orc = stmts(function_body(orc_text, "gaussianFilter"))
+    assert orc == ref, _diff(ref, orc)
+    ref = stmts(function_body(tex, "Texture::calculateSphericalCDF"), REF_RENAMES)
+    ref = mapped(ref, {
+        "float*funcU=new float[m_width*m_height];": ["const Texture&tex=o.sys.textures[2];", "const unsigned int m_width=tex.width,m_height=tex.height;",
+                                                      "const float*rgba=reinterpret_cast<const float*>(tex.texels);", "std::vector<float>funcU(m_width*m_height),funcV(m_height+1);"],
+        "float*funcV=new float[m_height+1];": None,
+        "m_integral=sum*2.0f*M_PIf_*M_PIf_/float(m_width*m_height);": "o.sys.envIntegral=sum*2.0f*M_PIf_*M_PIf_/float(m_width*m_height);",
+        "float*cdfU=new float[(m_width+1)*m_height];": ["o.sys.envCDF_U.assign((m_width+1)*m_height,0.0f);", "o.sys.envCDF_V.assign(m_height+1,0.0f);", "float*cdfU=o.sys.envCDF_U;"],
+        "float*cdfV=new float[m_height+1];": "float*cdfV=o.sys.envCDF_V;",
+        "funcV[m_height]=integral;": None,   # "For completeness, actually unused." (Texture.cpp:1613)
+        # upload and clean-up: the tables stay in the oracle's SystemData
+        "size_t sizeBytes=(m_width+1)*m_height*sizeof(float);": None, "CU_CHECK(cuMemAlloc(&m_d_envCDF_U,sizeBytes));": None, "CU_CHECK(cuMemcpyHtoD(m_d_envCDF_U,cdfU,sizeBytes));": None,
+        "sizeBytes=(m_height+1)*sizeof(float);": None, "CU_CHECK(cuMemAlloc(&m_d_envCDF_V,sizeBytes));": None, "CU_CHECK(cuMemcpyHtoD(m_d_envCDF_V,cdfV,sizeBytes));": None,
+        "delete[]cdfV;": None, "delete[]cdfU;": None, "delete[]funcV;": None, "delete[]funcU;": ["o.sys.envWidth=m_width;", "o.sys.envHeight=m_height;"],
+    })
+    orc = stmts(function_body(orc_text, "calculateSphericalCDF"), extra_spelling=CASTS + [(r"\.data\(\)", "")])
+    assert orc == ref, _diff(ref, orc)
+
+
+def test_screenshot_tonemap_loop(texts):
+    """Application::screenshot, tonemap branch (apps/rtigo3/src/Application.cpp:2259-2297) vs screenshotTonemap."""
+    app = read(os.path.join(REF_SRC, "Application.cpp"))
+    ren = [(r"fmaxf\(make_float3\(0\.0f\),", "fmaxf3v(make_float3(0.0f),"), (r"\bpowf\(ldrColor,", "powf3(ldrColor,"), (r"\bclamp\(powf3\(", "clamp3(powf3(")]
+    ref = stmts(function_body(app, "Application::screenshot"), ren)
+    ref = _between(ref, "const float invGamma=", "dst[idx]=make_uchar3(")
+    ref = mapped(ref, {   # the x / y loops over the image, flattened
+        "for(int y=0; y<m_resolution.y;++y)": "for(size_t idx=0; idx<numPixels;++idx)",
+        "for(int x=0; x<m_resolution.x;++x)": None,
+        "const int idx=y*m_resolution.x+x;": None,
+    })
+    orc = stmts(function_body(texts["orc_render"], "screenshotTonemap"))
+    assert orc == ref, _diff(ref, orc)
