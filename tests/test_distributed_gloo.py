@@ -65,3 +65,23 @@ def test_two_rank_gather_and_composite_equals_single(tmp_path, twk, orc):
         single.render(it)
     full = single.getOutputBufferHost()
     assert np.array_equal(composed.view(np.uint32), full.view(np.uint32))
+
+
+def test_bench_self_launch_relays_failure_without_a_gpu(twk):
+    """`python bench.py --gpus 2` with no external launcher starts its own ranks (child torch.distributed.run on 127.0.0.1)
+    and passes their exit code on: with no GPU every rank fails loudly in twk_device_create (there is no CPU path), so the
+    plain command must exit non-zero and print no result line. (On a GPU box: tests/test_gpu_bench_rehearsal.py.)"""
+    import subprocess
+    try:
+        if twk.device_count() > 0:
+            pytest.skip("a GPU is present")
+    except twk.TwkError:
+        pass
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse-gloo", "--no-roofline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "no CPU path" in out.stderr or "TwkError" in out.stderr or "ChildFailedError" in out.stderr, out.stderr[-1500:]

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 def _rehearse(ranks, extra=()):
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    port = 29600 + (os.getpid() % 300) + ranks
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "8", "--warmup", "3",
+    env.pop("WORLD_SIZE", None)
+    # the PLAIN command, no external launcher: bench.py starts its ranks itself (torch.distributed.run as a child process,
+    # before this process touches the GPU) and relays rank 0's line — what `python bench.py --gpus N` does on the 8-GPU node
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "8", "--warmup", "3",
            "--batch", "8", "--rehearse-gloo", "--no-roofline", *extra]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -40,6 +41,25 @@ def test_ranks_compose_the_single_device_image_of_c5(ranks):
     assert cfg["gather_bytes_per_rank"] == lw * 2160 * 16 and cfg["gather_plus_compositor_ms"] > 0
     assert cfg["composite_bit_identical_to_single_device"] is True
     assert cfg["crc32_composed"] == cfg["crc32_single_device"]
+    # where the timed region went: slowest rank's rendering + the one exchange step <= the whole
+    assert 0 < res["render_ms_max_rank"] <= res["ms_per_step"] * res["steps"] * 1.001
+    assert res["exchange_ms"] == cfg["gather_plus_compositor_ms"] > 0
+    assert res["value_render_only"] >= res["value"] > 0
+    assert res["metric"].endswith("3840x2160")
+
+
+def test_external_launcher_still_works():
+    """The driver's other form: python -m torch.distributed.run ... bench.py --gpus N (WORLD_SIZE set: no self-launch)."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--batch", "4", "--rehearse-gloo", "--no-roofline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["composite_bit_identical_to_single_device"] is True
 
 
 def test_two_ranks_weak_mode():
