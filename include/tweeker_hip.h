@@ -27,7 +27,7 @@ extern "C" {
 
 /* 3: TwkLaunchStats grew by waveCycles[6] (twk_stats_get writes sizeof(TwkLaunchStats) bytes) and
  * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
-#define TWK_ABI_VERSION 3
+#define TWK_ABI_VERSION 4
 
 typedef enum TwkResult
 {
@@ -227,6 +227,7 @@ typedef struct TwkBuildInfo
   double   sahLeafCost;
   double   buildMilliseconds; /* host wall time of twk_build, uploads included */
   uint64_t triangleSlots, nodes, instances, flattenedInstances;
+  uint64_t maxTraversalDepth; /* ABI 4: binary-tree levels of the deepest root-to-leaf path (top level + the deepest tree below it); twk_build refuses a scene deeper than the traversal stacks */
 } TwkBuildInfo;
 int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info);
 

@@ -267,3 +267,28 @@ def test_persistent_kernel_against_oracle_on_adversarial_rays(twk, orc, system, 
     assert np.array_equal(occ, s_ids[:, 0]), f"{(occ != s_ids[:, 0]).sum()} occlusion flags differ"
     assert 0.02 < occ.mean() < 0.98
     dev.close()
+
+
+def test_tree_height_is_measured_and_a_scene_beyond_the_stacks_is_refused(twk, monkeypatch):
+    """the SAH builder may peel one primitive per level; a tree deeper than the traversal stacks
+    (20 LDS + 72 HBM entries, trace_device.h) would drop subtrees without a word. twk_build measures the binary-tree
+    height in its refit pass, reports it (TwkBuildInfo.maxTraversalDepth) and refuses a scene beyond the stacks; the
+    limit can only be lowered (TWK_MAX_TRAVERSAL_DEPTH), which is how the refusal is exercised here."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (32, 32))
+    for quality in (0, 1):
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        dev.setBuildQuality(quality)
+        app.initDevice(dev)
+        info = dev.buildInfo()
+        # 32,040 triangles per sphere, leaves of <= 2: at least log2(16,020) = 14 levels below a top level of >= 3
+        assert 17 <= info["maxTraversalDepth"] <= 64, info
+        dev.close()
+    monkeypatch.setenv("TWK_MAX_TRAVERSAL_DEPTH", "8")
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    with pytest.raises(twk.TwkError) as e:
+        app.initDevice(dev)
+    assert "levels deep" in str(e.value) and "traversal stacks hold 92" in str(e.value)
+    with pytest.raises(twk.TwkError):
+        dev.render(0)
+        dev.synchronizeStream()
+    dev.close()

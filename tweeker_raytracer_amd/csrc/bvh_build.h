@@ -40,6 +40,9 @@ public:
   // over its leaf primitives), measured after every build.
   double lastSahInner() const { return m_lastSahInner; }
   double lastSahLeaf() const { return m_lastSahLeaf; }
+  // Height of the binary tree built last (inner nodes on the longest root-to-leaf path, after the leaf collapse): what a
+  // single-ray traversal may have to keep on its stack.
+  int    lastHeight() const { return m_lastHeight; }
   void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 4) ? 4 : n); } // count - 1 takes two bits of a leaf reference
 
 private:
@@ -68,6 +71,7 @@ private:
   unsigned int* m_sahCb = nullptr; unsigned int* m_sahBins = nullptr; unsigned int* m_sahFill = nullptr;
   int* m_sahCounters = nullptr; double* m_sahCost = nullptr;
   double m_lastSahInner = 0.0, m_lastSahLeaf = 0.0;
+  int    m_lastHeight = 0;
   void* m_sortTemp = nullptr; size_t m_sortBytes = 0;
 };
 

@@ -275,6 +275,7 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
     const int l = left[node], r = right[node];
     float4 lo0, hi0, lo1, hi1;
     int c0, c1;
+    int height0 = 0, height1 = 0; // height of the FINAL binary tree below each child (a collapsed subtree is a leaf: 0), kept in nodeLo[].w
     if (l < 0)
     {
       const unsigned int prim = (unsigned int) (keys[~l] & 0xffffffffull);
@@ -286,6 +287,7 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
       lo0 = nodeLo[l]; hi0 = nodeHi[l];
       const int2 rg = range[l];
       c0 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28) | leafFlag) : nodeBase + l;
+      if (c0 >= 0) height0 = __float_as_int(lo0.w);
     }
     if (r < 0)
     {
@@ -298,6 +300,7 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
       lo1 = nodeLo[r]; hi1 = nodeHi[r];
       const int2 rg = range[r];
       c1 = (leafMode == 0 && rg.y <= maxLeaf) ? ~((leafBase + rg.x) | ((rg.y - 1) << 28) | leafFlag) : nodeBase + r;
+      if (c1 >= 0) height1 = __float_as_int(lo1.w);
     }
     writeNode(&outNodes[node], lo0, hi0, lo1, hi1, c0, c1);
     {
@@ -308,7 +311,7 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
       for (; n < 4; ++n) emptyEntry(e[n]);
       writeWideNode(&outWide[2 * node], e);
     }
-    nodeLo[node] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
+    nodeLo[node] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), __int_as_float(1 + max(height0, height1)));
     nodeHi[node] = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
     node = innerParent[node];
   }
@@ -329,6 +332,7 @@ __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4
   e[0].lo = lo; e[0].hi = hi; e[0].ref = leafRef;
   emptyEntry(e[1]); emptyEntry(e[2]); emptyEntry(e[3]);
   writeWideNode(outWide, e);
+  lo.w = __int_as_float(1); // height of this one-node tree (refitKernel keeps heights in nodeLo[].w)
   nodeLo[0] = lo; nodeHi[0] = hi;
 }
 
@@ -574,6 +578,7 @@ hipError_t BvhBuilder::buildTriangles(hipStream_t stream, const float* attribute
   BVH_CHECK(hipStreamSynchronize(stream));
   rootBounds[0] = lo.x; rootBounds[1] = lo.y; rootBounds[2] = lo.z;
   rootBounds[3] = hi.x; rootBounds[4] = hi.y; rootBounds[5] = hi.z;
+  { int h; memcpy(&h, &lo.w, sizeof(h)); m_lastHeight = h; }
   return hipSuccess;
 }
 
@@ -593,7 +598,10 @@ hipError_t BvhBuilder::buildInstances(hipStream_t stream, const float4* hostLo, 
   hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, m_bounds);
   hipLaunchKernelGGL(boxBoundsKernel, dim3(grid), dim3(block), 0, stream, m_primLo, m_primHi, numInstances, m_bounds);
   BVH_CHECK(buildFromBoxes(stream, numInstances, outNodes, outWide, nodeBase, 1, 0, 0));
+  float4 lo;
+  BVH_CHECK(hipMemcpyAsync(&lo, m_nodeLo, sizeof(float4), hipMemcpyDeviceToHost, stream));
   BVH_CHECK(hipStreamSynchronize(stream)); // hostLo/hostHi may go away
+  { int h; memcpy(&h, &lo.w, sizeof(h)); m_lastHeight = h; }
   return hipSuccess;
 }
 

@@ -457,11 +457,16 @@ hipError_t BvhBuilder::buildSahTopology(hipStream_t stream, int count)
   hipLaunchKernelGGL(sahInitKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[0], m_sahSlot[0], count > SAH_SMALL ? 1 : 0);
   int cur = 0;
   int numActive = (count > SAH_SMALL) ? 1 : 0;
-  for (int level = 0; numActive > 0 && level < 192; ++level)
+  for (int level = 0; numActive > 0 && level < 40 + 34; ++level)
   {
     const int next = cur ^ 1;
-    const int forceMiddle = (level >= 96) ? 1 : 0; // a degenerate input that SAH keeps peeling one primitive off: halve positions from here on
-    hipLaunchKernelGGL(sahClearKernel, dim3(std::min(4096, (numActive * (6 + 3 * SAH_BINS * SAH_BIN_WORDS + 2) + 255) / 256)), dim3(256), 0, stream, numActive, m_sahCb, m_sahBins, m_sahFill);
+    // A degenerate input that SAH keeps peeling one primitive off must not grow a tree deeper than the traversal stacks
+    // (trace_device.h: 20 LDS + 72 HBM entries): from level 40 on ranges are halved by position, which ends every range
+    // within log2(count) further levels. (Scenes of millions of triangles finish their SAH levels in 25-35.) twk_build
+    // measures the height that results and refuses a scene whose top + bottom height exceeds the stack capacity.
+    const int forceMiddle = (level >= 40) ? 1 : 0;
+    const long long clearWords = (long long) numActive * (6 + 3 * SAH_BINS * SAH_BIN_WORDS + 2); // 344 words per node: beyond int at ~6.2 M active nodes
+    hipLaunchKernelGGL(sahClearKernel, dim3((unsigned int) std::min<long long>(4096, (clearWords + 255) / 256)), dim3(256), 0, stream, numActive, m_sahCb, m_sahBins, m_sahFill);
     hipLaunchKernelGGL(sahBoundsKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb);
     hipLaunchKernelGGL(sahBinKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb, m_sahBins);
     hipLaunchKernelGGL(sahSelectKernel, dim3((numActive + 63) / 64), dim3(64), 0, stream, numActive, active[cur], m_sahBins, forceMiddle, split, nodeCounter,

@@ -116,6 +116,7 @@ struct TwkDevice_t
   bool outputFrame = false; // the external buffer is a shared full frame (twk_set_shared_frame)
   unsigned int* d_counters = nullptr;
   unsigned long long* d_stats = nullptr;
+  unsigned int* h_dropped = nullptr; unsigned int* d_dropped = nullptr; // pinned + device-mapped: LaunchParams::droppedPushes
   int* d_spill = nullptr; size_t spillLanes = 0;
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
   // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
@@ -253,6 +254,7 @@ static void refreshParams(TwkDevice dev)
   p.firstHit = dev->captureFirstHits ? dev->d_firstHit : nullptr;
   p.firstHitInstance = dev->captureFirstHits ? dev->d_firstHitInstance : nullptr;
   p.traceStackSpill = dev->d_spill;
+  p.droppedPushes = dev->d_dropped;
 }
 
 static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * TWK_TRACE_WAVES; } // every block resident at once (device_types.h)
@@ -312,6 +314,12 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
   }
   if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
   if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 24)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 24, dev->stream)); }
+  if (!dev->h_dropped)
+  {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->h_dropped), sizeof(unsigned int), hipHostMallocMapped));
+    *dev->h_dropped = 0u;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev->d_dropped), dev->h_dropped, 0));
+  }
   const size_t lanes = (size_t) traceGridBlocks(dev) * TWK_TRACE_BLOCK;
   if (lanes > dev->spillLanes)
   {
@@ -372,6 +380,17 @@ static int collectTimed(TwkDevice dev)
   }
   dev->timedUsed = 0;
   return TWK_SUCCESS;
+}
+
+// After a stream synchronisation: did any traversal lose a push (trace_device.h TWK_PUSH)? Cannot happen on a scene
+// twk_build accepted; if it does, the image is wrong and the caller must hear about it, statistics on or off.
+static int checkDroppedPushes(TwkDevice dev, const char* where)
+{
+  if (!dev->h_dropped || *dev->h_dropped == 0u) return TWK_SUCCESS;
+  const unsigned int n = *dev->h_dropped;
+  *dev->h_dropped = 0u;
+  return twkSetError(TWK_ERROR_INVALID_STATE, std::string(where) + ": " + std::to_string(n) + " traversal stack pushes were dropped (tree deeper than the " +
+                     std::to_string(TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) + "-entry stacks): the image is incomplete");
 }
 
 // Spherical environment CDFs + integral, Texture.cpp:1499-1645.
@@ -587,6 +606,7 @@ try
   freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
   freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
+  if (dev->h_dropped) { (void) hipHostFree(dev->h_dropped); dev->h_dropped = nullptr; dev->d_dropped = nullptr; }
   freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
   freeDevice(dev->d_pathAlbedo); freeDevice(dev->d_pathNormal); freeDevice(dev->d_aovAlbedo); freeDevice(dev->d_aovNormal);
   dev->builder.release();
@@ -905,6 +925,7 @@ try
   }
 
   if (const char* e = getenv("TWK_MAX_LEAF")) dev->builder.setMaxLeaf(atoi(e)); // tuning knob, default 2 triangles per leaf
+  int maxEnteredHeight = 0, maxFlatHeight = 0, topHeight = 0; // binary-tree heights: what a traversal stack may have to hold
   // bottom level: one LBVH per entered geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
   for (size_t k = 0; k < dev->geometries.size(); ++k)
   {
@@ -913,6 +934,7 @@ try
     HIP_TRY(dev->builder.buildTriangles(dev->stream, dev->d_attributes + 12 * (size_t) g.attributeBase, dev->d_indices + g.indexBase, g.numTriangles,
                                         dev->d_nodes + g.nodeBase, dev->d_wideNodes + 2 * (size_t) g.nodeBase, g.nodeBase, dev->d_triangles, dev->d_shadeTriangles, g.triangleBase, g.rootBounds));
     info.sahInnerCost += dev->builder.lastSahInner(); info.sahLeafCost += dev->builder.lastSahLeaf(); info.trees += 1;
+    maxEnteredHeight = std::max(maxEnteredHeight, dev->builder.lastHeight());
   }
 
   // instance records (shading reads them for every hit, flattened or not)
@@ -949,6 +971,7 @@ try
                                           dev->d_nodes + flatNodeBase[i], dev->d_wideNodes + 2 * (size_t) flatNodeBase[i], flatNodeBase[i],
                                           dev->d_triangles, dev->d_shadeTriangles, flatTriangleBase[i], bounds, soup.ptr, dev->d_instances));
       info.sahInnerCost += dev->builder.lastSahInner(); info.sahLeafCost += dev->builder.lastSahLeaf(); info.trees += 1;
+      maxFlatHeight = std::max(maxFlatHeight, dev->builder.lastHeight());
       boxLo[i] = make_float4(bounds[0], bounds[1], bounds[2], 0.0f);
       boxHi[i] = make_float4(bounds[3], bounds[4], bounds[5], 0.0f);
       leafPayload[i] = ~flatNodeBase[i]; // child reference ~payload = the instance's root node: an inner reference
@@ -977,6 +1000,21 @@ try
   {
     HIP_TRY(dev->builder.buildInstances(dev->stream, boxLo.data(), boxHi.data(), leafPayload.data(), numInstances, dev->d_nodes + tlasBase, dev->d_wideNodes + 2 * (size_t) tlasBase, tlasBase));
     dev->tlasRoot = tlasBase;
+    topHeight = dev->builder.lastHeight();
+  }
+  // Deepest stack a single-ray traversal can need (trace_device.h traverse(): at most one push per inner node on the path,
+  // plus the sentinel of an instance entry): the top level, then either a spliced world-space tree or an entered
+  // geometry's tree. The persistent kernel hands rays that outgrow its LDS stack to that traversal, whose stack holds
+  // TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL entries; a scene beyond that would lose subtrees silently, so it is refused.
+  const int traversalDepth = topHeight + std::max(maxFlatHeight, (numEntered > 0) ? 1 + maxEnteredHeight : 0);
+  int depthLimit = TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL - 2;
+  if (const char* e = getenv("TWK_MAX_TRAVERSAL_DEPTH")) depthLimit = std::min(depthLimit, atoi(e)); // test hook: a lower limit only
+  if (traversalDepth > depthLimit)
+  {
+    dev->built = false;
+    return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_build: the acceleration structure is " + std::to_string(traversalDepth) + " levels deep (top " + std::to_string(topHeight) +
+                       ", flattened trees " + std::to_string(maxFlatHeight) + ", entered geometries " + std::to_string(maxEnteredHeight) + "); the traversal stacks hold " +
+                       std::to_string(TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) + " entries" + (dev->builder.quality() == TWK_BUILD_SAH ? " (try twk_set_build_quality(TWK_BUILD_LBVH))" : ""));
   }
   // the persistent trace kernel reads the quantised copy of the wide nodes; the full-precision ones were scratch
   launchQuantizeWide(dev->d_wideNodes, dev->d_wideQ, (int) numNodes, dev->stream);
@@ -986,6 +1024,7 @@ try
   HIP_TRY(hipStreamSynchronize(dev->stream));
   freeDevice(dev->d_wideNodes);
 
+  info.maxTraversalDepth = (uint64_t) traversalDepth;
   info.triangleSlots = numTris; info.nodes = numNodes; info.instances = (uint64_t) numInstances; info.flattenedInstances = (uint64_t) (numInstances - numEntered);
   info.buildMilliseconds = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
   dev->buildInfo = info;
@@ -1052,7 +1091,7 @@ try
 {
   int rc = activate(dev, "twk_sync"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  return TWK_SUCCESS;
+  return checkDroppedPushes(dev, "twk_sync");
 }
 TWK_CATCH("twk_sync")
 
@@ -1076,7 +1115,7 @@ try
   if (!src) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_read_output: nothing has been rendered");
   HIP_TRY(hipStreamSynchronize(dev->stream));
   HIP_TRY(hipMemcpy(rgbaHost, src, n * sizeof(float4), hipMemcpyDeviceToHost));
-  return TWK_SUCCESS;
+  return checkDroppedPushes(dev, "twk_read_output");
 }
 TWK_CATCH("twk_read_output")
 
@@ -1248,7 +1287,7 @@ try
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
   stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
   stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
-  stats->cachedNodesVisited = h[16]; stats->droppedStackPushes = h[17];
+  stats->cachedNodesVisited = h[16]; stats->droppedStackPushes = dev->h_dropped ? *dev->h_dropped : 0u;
   for (int i = 0; i < 6; ++i) stats->waveCycles[i] = h[18 + i];
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;

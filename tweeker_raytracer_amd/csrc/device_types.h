@@ -204,6 +204,7 @@ struct LaunchParams
   int     numPixels;      // launchWidth * height = launch indices of ONE sample per pixel
   int     numPaths;       // numPixels * batchCount: paths of this wavefront pass, path = sample * numPixels + launch index
   int     batchCount;     // iterations rendered together (iterationIndex .. iterationIndex + batchCount - 1)
+  unsigned int* droppedPushes; // pinned host word (device-mapped): pushes the single-ray traversal could not store (trace_device.h TWK_PUSH); stays 0 on every scene twk_build accepts
 };
 
 // Counter block layout (unsigned int each), zeroed once per launch.

@@ -172,9 +172,10 @@ TWK_D void traverse(const LaunchParams& p, const V3& org, const V3& dir, float t
   unsigned int guard = 0; // a well-formed tree never gets near this; keeps a corrupted one from hanging the GPU
 
   // A push beyond LDS + HBM capacity (20 + 72 entries of a binary traversal: a tree more than ~90 levels deep along one
-  // path) cannot be stored; the pop then yields the sentinel and the subtree is lost. Counted in stats[17] when the
-  // device keeps statistics, so that a truncated traversal is visible (twk_stats_get: droppedStackPushes).
-#define TWK_PUSH(v) do { if (sp < TWK_TRACE_STACK_LDS) ldsStack[sp * stride] = (v); else if (sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) spill[sp - TWK_TRACE_STACK_LDS] = (v); else if (p.stats != nullptr) atomicAdd(&p.stats[17], 1ull); ++sp; } while (0)
+  // path) cannot be stored; the pop then yields the sentinel and the subtree is lost. twk_build refuses scenes that deep
+  // (device_api.hip: traversalDepth), so this cannot happen on a built scene; should it ever, the push is counted in a
+  // word of pinned host memory whether or not statistics are on, and the next twk_sync / twk_read_output fails.
+#define TWK_PUSH(v) do { if (sp < TWK_TRACE_STACK_LDS) ldsStack[sp * stride] = (v); else if (sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) spill[sp - TWK_TRACE_STACK_LDS] = (v); else __hip_atomic_fetch_add(p.droppedPushes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ++sp; } while (0)
 #define TWK_POP(v)  do { --sp; (v) = (sp < TWK_TRACE_STACK_LDS) ? ldsStack[sp * stride] : ((sp < TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) ? spill[sp - TWK_TRACE_STACK_LDS] : TWK_BVH_SENTINEL); } while (0)
 
   for (;;)
