@@ -71,7 +71,7 @@ def self_launch(n_gpus, argv):
     return proc.wait()
 
 
-def pick_pmc_record(steps, batch_depth, resolution):
+def pick_pmc_record(steps, batch_depth, resolution, sphere_tess=180):
     """HBM-side bytes come from rocprofv3 --pmc passes (tools/pmc_collect.sh + tools/pmc_traffic.py), which cannot run
     inside this process. A committed record is carried ONLY when it was taken at this run's launch size: same steps,
     same batch depth, same resolution. Newest record (by name) wins. Returns (record, file name) or (None, reason)."""
@@ -83,9 +83,10 @@ def pick_pmc_record(steps, batch_depth, resolution):
                 rec = json.load(f)
         except Exception:
             continue
-        if rec.get("steps") == steps and rec.get("batch_depth") == batch_depth and rec.get("resolution") == list(resolution):
+        if (rec.get("steps") == steps and rec.get("batch_depth") == batch_depth and rec.get("resolution") == list(resolution)
+                and rec.get("sphere_tess", 180) == sphere_tess):
             return rec, os.path.basename(path)
-        seen.append(f"{os.path.basename(path)}: steps {rec.get('steps')} batch {rec.get('batch_depth')} {rec.get('resolution')}")
+        seen.append(f"{os.path.basename(path)}: steps {rec.get('steps')} batch {rec.get('batch_depth')} {rec.get('resolution')} tess {rec.get('sphere_tess', 180)}")
     return None, "no PMC record at this launch size (have: " + "; ".join(seen) + ")" if seen else "no PMC record under profiles/"
 
 
@@ -99,6 +100,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="iterations rendered together per wavefront pass (twk_set_launch_batch, 1..64)")
     ap.add_argument("--weak", action="store_true", help="N > 1: round 1's weak-scaling frame (N x 2,073,600 pixels) instead of the fixed C5 frame")
     ap.add_argument("--c5", action="store_true", help="N = 1: render the C5 frame (3840x2160) instead of C2 — the one-GPU point of the strong-scaling curve")
+    ap.add_argument("--sphere-tess", type=int, default=180,
+                    help="N = 1: tessellation of the two spheres of the Cornell scene (`model sphere U U/2`): 180 is the scene file as it stands (64 k triangles, "
+                         "cache-resident); 1000 gives 2.0 M and 2800 gives 15.7 M triangles — a scene the caches do not hold, where the HBM roofline applies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-composite-check", action="store_true")
@@ -138,7 +142,12 @@ def main():
     device = torch.device("cuda", local_rank)
     c5 = (n_gpus > 1 and not args.weak) or (n_gpus == 1 and args.c5)
     system = args.system or os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box_c5.txt" if c5 else "system_rtigo3_cornell_box.txt")
-    app = twk.Application(system, args.scene)
+    if args.sphere_tess != 180:
+        scene_text = open(args.scene).read().replace("sphere 180 90", f"sphere {args.sphere_tess} {args.sphere_tess // 2}")
+        assert "sphere 180 90" in open(args.scene).read(), "--sphere-tess expects the Cornell scene file"
+        app = twk.Application(system_text=open(system).read(), scene_text=scene_text)
+    else:
+        app = twk.Application(system, args.scene)
     if n_gpus > 1 and args.weak:
         app.setResolution(*weak_frame_for(n_gpus))
     info = app.info
@@ -240,6 +249,8 @@ def main():
         workload = "C2 grown for weak scaling: Cornell box, 16:9 frame of N x 2,073,600 pixels"
     else:
         workload = "C2: Cornell box (scene_rtigo3_cornell_box.txt: Lambert + GGX wall + mirror + glass spheres, 64,096 triangles, 8 instances)"
+        if args.sphere_tess != 180:
+            workload = f"C2 room with the two spheres tessellated {args.sphere_tess} x {args.sphere_tess // 2} (NOT the baseline configuration: a scene the caches do not hold, for the HBM roofline)"
     result = {
         "metric": f"Msamples/s (paths x spp x res / s), Cornell box {width}x{height}",
         "value": samples / elapsed / 1.0e6,
@@ -317,7 +328,7 @@ def main():
         algo_gbps = algo_bytes / trace_s / 1.0e9
         gather_gbps = lane_loads * 16 / trace_s / 1.0e9
         avg_launch_s = trace_s / trace_launches
-        pmc, pmc_source = (None, "N > 1") if n_gpus != 1 else pick_pmc_record(args.steps, result["config"]["batch_depth"], (width, height))
+        pmc, pmc_source = (None, "N > 1") if n_gpus != 1 else pick_pmc_record(args.steps, result["config"]["batch_depth"], (width, height), args.sphere_tess)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         hbm_side_gbps = (traffic / avg_launch_s / 1.0e9) if traffic else None
         bi = dev.buildInfo()
@@ -348,11 +359,16 @@ def main():
                 "hbm_side_frac_of_measured_stream_peak": (hbm_side_gbps / stream_peak) if hbm_side_gbps else None,
                 "algorithmic_frac_of_spec": algo_frac_spec,
                 "algorithmic_frac_of_measured_stream_peak": algo_gbps / stream_peak,
-                "met": bool(hbm_side_gbps and hbm_side_gbps / stream_peak >= 0.70),
+                # two readings of "70 % of the measured HBM roofline": SURVEY 8(d) prices ALGORITHMIC bytes (cache hits not deducted);
+                # the HBM-side reading asks what the memory actually carried. On a cache-resident scene the first is no bound
+                # and the second cannot be reached; on a scene the caches do not hold both mean something.
+                "met_by_algorithmic_bytes_vs_measured_stream_peak": bool(algo_gbps / stream_peak >= 0.70),
+                "met_by_hbm_side_bytes_vs_measured_stream_peak": bool(hbm_side_gbps and hbm_side_gbps / stream_peak >= 0.70),
+                "met": bool((not cache_resident) and algo_gbps / stream_peak >= 0.70),
                 "scene_cache_resident": cache_resident,
                 "note": ("the Cornell scene's nodes and triangles sit in L2 / Infinity Cache: HBM carries only the ray / hit streams, so the HBM-side fraction cannot reach 0.70 on this scene whatever the kernel does, "
                          "while the algorithmic fraction passes it without being a bound; the target is testable only on a scene that is not cache-resident (tools/big_scene_probe.py, profiles/r03_big_scene_pmc.md)"
-                         if cache_resident else "scene larger than the caches: the HBM-side fraction is the meaningful one"),
+                         if cache_resident else "scene larger than the caches (nodes + triangles exceed the 256 MiB Infinity Cache): both fractions are meaningful here; `met` = the SURVEY 8(d) reading on this scene"),
             },
             "hbm_side": {"bytes_per_launch": traffic, "achieved_gbps": hbm_side_gbps,
                          "l2_hit_rate": pmc.get("l2_hit_rate") if pmc else None,

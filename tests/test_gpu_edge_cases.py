@@ -5,6 +5,8 @@ LDS traversal stack. All against the oracle's brute force, bit for bit."""
 import numpy as np
 import pytest
 
+from conftest import load_app
+
 pytestmark = pytest.mark.gpu
 
 

@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=None); ap.add_argument("--warmup", 
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--resolution", type=int, nargs=2, default=[1920, 1080])
 ap.add_argument("--kernel", default="traceKernel<false")
+ap.add_argument("--sphere-tess", type=int, default=180)
 a = ap.parse_args()
 if a.steps is None:
     sw = os.path.join(a.root, "steps_warmup.txt")
@@ -41,13 +42,14 @@ for path in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), rec
 g = lambda c: per.get(c, 0.0)
 res = {
     "kernel": "twk::traceKernel<false, false, *>",
-    "steps": a.steps, "warmup": a.warmup, "batch_depth": batch, "resolution": list(a.resolution),
+    "steps": a.steps, "warmup": a.warmup, "batch_depth": batch, "resolution": list(a.resolution), "sphere_tess": a.sphere_tess,
     "dispatches_averaged_of_all": used.get("FETCH_SIZE"),
     "fetch_size_kib_per_launch": g("FETCH_SIZE"),
     "write_size_kib_per_launch": g("WRITE_SIZE"),
     "fetch_correction": 2.0,
     "hbm_bytes_per_launch": (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0,
     "l2_hit_rate": g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum")),
+    "l2_hits_per_launch": g("TCC_HIT_sum"), "l2_misses_per_launch": g("TCC_MISS_sum"),
     # per wave: share of its cycles parked on memory / waiting for an issue slot / issuing
     "wave_cycles_waiting_on_memory": g("SQ_WAIT_ANY") / max(1.0, g("SQ_WAVE_CYCLES")),
     "wave_cycles_waiting_for_issue": g("SQ_WAIT_INST_ANY") / max(1.0, g("SQ_WAVE_CYCLES")),

@@ -74,6 +74,8 @@ struct InstanceHost
 };
 
 struct TimedLaunch { hipEvent_t start, stop; int kind; };
+#define TWK_MAX_LANES 4
+#define TWK_COUNTER_WORDS (TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)) // one lane's counter block
 
 struct TwkDevice_t
 {
@@ -137,6 +139,16 @@ struct TwkDevice_t
   unsigned int pendingFirst = 0;
   int   pendingCount = 0;
   int   allocatedPaths = 0;
+
+  // Pass lanes: a wavefront pass may be cut into up to TWK_MAX_LANES independent sub-passes over disjoint path ranges, each a
+  // chain of generate / trace / shade launches on a stream of its own (lane 0 = `stream`), joined before the accumulate
+  // kernel. Small passes are bound by the dependent-launch chain and the longest ray of each launch, not by throughput:
+  // two chains side by side fill each other's gaps (renderPass).
+  hipStream_t laneStream[TWK_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t  laneDone[TWK_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t  laneFork = nullptr;
+  int   lanesForced = 0; // TWK_PASS_LANES: 0 = choose by pass size
+  int   laneTraceWaves = 0; // TWK_LANE_TRACE_WAVES: trace blocks per CU of each lane (0 = TWK_TRACE_WAVES / lanes)
 
   LaunchParams params;
   BvhBuilder builder;
@@ -244,6 +256,7 @@ static void refreshParams(TwkDevice dev)
   p.numPixels = dev->launchWidth * dev->state.resolution[1];
   p.batchCount = 1;
   p.numPaths = p.numPixels;
+  p.pathBase = 0;
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   p.outputFrame = (dev->d_outputExternal && dev->outputFrame) ? 1 : 0;
   p.counters = dev->d_counters;
@@ -312,7 +325,7 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
       dev->aovPixels = dev->allocatedPixels;
     }
   }
-  if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
+  if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTER_WORDS * TWK_MAX_LANES));
   if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 24)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 24, dev->stream)); }
   if (!dev->h_dropped)
   {
@@ -320,7 +333,7 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     *dev->h_dropped = 0u;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev->d_dropped), dev->h_dropped, 0));
   }
-  const size_t lanes = (size_t) traceGridBlocks(dev) * TWK_TRACE_BLOCK;
+  const size_t lanes = (size_t) 2 * traceGridBlocks(dev) * TWK_TRACE_BLOCK; // two full grids: the lanes of a pass may each be given more than their share of a grid (TWK_LANE_TRACE_WAVES)
   if (lanes > dev->spillLanes)
   {
     freeDevice(dev->d_spill);
@@ -347,7 +360,7 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
   return TWK_SUCCESS;
 }
 
-static void timedLaunchBegin(TwkDevice dev, int kind)
+static void timedLaunchBegin(TwkDevice dev, int kind, hipStream_t stream)
 {
   if (!dev->profileEnabled) return;
   if (dev->timedUsed == dev->timed.size())
@@ -357,13 +370,13 @@ static void timedLaunchBegin(TwkDevice dev, int kind)
     dev->timed.push_back(t);
   }
   dev->timed[dev->timedUsed].kind = kind;
-  (void) hipEventRecord(dev->timed[dev->timedUsed].start, dev->stream);
+  (void) hipEventRecord(dev->timed[dev->timedUsed].start, stream);
 }
 
-static void timedLaunchEnd(TwkDevice dev)
+static void timedLaunchEnd(TwkDevice dev, hipStream_t stream)
 {
   if (!dev->profileEnabled) return;
-  (void) hipEventRecord(dev->timed[dev->timedUsed].stop, dev->stream);
+  (void) hipEventRecord(dev->timed[dev->timedUsed].stop, stream);
   dev->timedUsed++;
 }
 
@@ -484,6 +497,41 @@ static int flushPending(TwkDevice dev)
   return TWK_SUCCESS;
 }
 
+// How many lanes a pass of `numPaths` paths is cut into (TWK_PASS_LANES forces a count). Measured on C2, DESIGN.md 2.
+static int chooseLanes(TwkDevice dev, int numPaths)
+{
+  int lanes = 1;
+  if (dev->lanesForced > 0) lanes = dev->lanesForced;
+  else if (numPaths <= TWK_LANES2_MAX_PATHS) lanes = 2;
+  if (dev->captureFirstHits || dev->tailDepth > 0) lanes = 1; // debug capture indexes by launch index; the tail kernel owns the whole grid
+  while (lanes > 1 && numPaths / lanes < 4096) --lanes;
+  return std::min(lanes, TWK_MAX_LANES);
+}
+
+// The launch parameters of lane `lane` of `lanes`: paths [base, base + count) of the pass, every per-path and per-slot
+// stream offset to the lane's own range, a counter block and a slice of the traversal spill stacks of its own.
+static LaunchParams laneParams(TwkDevice dev, const LaunchParams& p, int lane, int lanes, int traceBlocks)
+{
+  if (lanes == 1) return p;
+  LaunchParams q = p;
+  const size_t total = (size_t) p.numPaths;
+  const size_t share = ((total + lanes - 1) / lanes + 1023) & ~(size_t) 1023;
+  const size_t base = std::min(total, share * lane), count = std::min(total - base, share);
+  q.pathBase = (int) base; q.numPaths = (int) count;
+  for (int k = 0; k < 2; ++k)
+  {
+    q.rayOrg[k] += base; q.rayDir[k] += base; q.rayPixel[k] += base; q.rayThroughput[k] += base; q.raySeedFlags[k] += base;
+  }
+  q.hitRecord += base; q.hitInstance += base;
+  q.shadowOrg += base; q.shadowDir += base; q.shadowPixel += base; q.shadowPending += base;
+  q.pathRadiance += base; q.overflowSlots += 2 * base;
+  q.volumeStack += 4 * base; // [4][numPaths of the lane], indexed level * numPaths + path (shade_device.h)
+  if (q.pathAlbedo) { q.pathAlbedo += base; q.pathNormal += base; }
+  q.counters = dev->d_counters + (size_t) lane * TWK_COUNTER_WORDS;
+  q.traceStackSpill = dev->d_spill + (size_t) lane * traceBlocks * TWK_TRACE_BLOCK * TWK_TRACE_STACK_SPILL;
+  return q;
+}
+
 // Runs iterations [firstIteration, firstIteration + count) as one wavefront pass; the streams are allocated.
 static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
 {
@@ -492,38 +540,74 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   p.iterationIndex = firstIteration;
   p.batchCount = count;
   p.numPaths = p.numPixels * p.batchCount;
+  p.pathBase = 0;
 
   const int maxDepth = dev->state.pathLengths[1];
-  HIP_TRY(hipMemsetAsync(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2), dev->stream));
-
-  const int traceGrid = traceGridBlocks(dev);
-  int shadeGrid = (p.numPaths + TWK_SHADE_BLOCK - 1) / TWK_SHADE_BLOCK;
-  // Many more blocks than are resident at once (4 per CU): a block that has finished its windows makes room for the next,
-  // which evens out what the blocks' windows cost. Measured on C2 (shade ms/step): 4 / 8 / 16 / 64 / 256 / 2048 blocks per
-  // CU = 0.310 / 0.309 / 0.305 / 0.294 / 0.290 / 0.298.
-  if (shadeGrid > dev->numCUs * TWK_SHADE_BLOCKS_PER_CU) shadeGrid = dev->numCUs * TWK_SHADE_BLOCKS_PER_CU;
+  const int lanes = chooseLanes(dev, p.numPaths);
+  // every block of every lane's persistent trace kernel resident at once: the lanes share the CUs' block slots
+  int traceWaves = std::max(1, TWK_TRACE_WAVES / lanes);
+  if (lanes > 1 && dev->laneTraceWaves > 0) traceWaves = std::min(dev->laneTraceWaves, 2 * TWK_TRACE_WAVES / lanes); // TWK_LANE_TRACE_WAVES (experiments; the spill stacks hold two full grids)
+  const int traceGrid = dev->numCUs * traceWaves;
 
   // Bounces [0, wavefrontDepth) run as per-depth trace/shade launches over compacted queues; the remaining bounces
   // of every surviving path run inside one persistent tail kernel (tail_kernel.hip).
   int wavefrontDepth = maxDepth;
   if (dev->tailDepth > 0 && dev->tailDepth < maxDepth) wavefrontDepth = dev->tailDepth;
 
-  timedLaunchBegin(dev, TWK_KERNEL_GENERATE); launchGenerate(p, dev->stream); timedLaunchEnd(dev);
+  if (lanes > 1)
+  {
+    if (!dev->laneFork) HIP_TRY(hipEventCreateWithFlags(&dev->laneFork, hipEventDisableTiming));
+    for (int k = 1; k < lanes; ++k)
+    {
+      if (!dev->laneStream[k]) HIP_TRY(hipStreamCreateWithFlags(&dev->laneStream[k], hipStreamNonBlocking));
+      if (!dev->laneDone[k]) HIP_TRY(hipEventCreateWithFlags(&dev->laneDone[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(dev->laneFork, dev->stream)); // everything the handle's stream holds so far (uploads, the previous pass's accumulate)
+  }
+  // The chains are enqueued side by side, step by step (lane 0's kernel k, lane 1's kernel k, ...): enqueued one whole chain
+  // after the other, the second lane would start a chain's worth of host launch time behind the first.
+  LaunchParams laneP[TWK_MAX_LANES];
+  hipStream_t laneS[TWK_MAX_LANES];
+  int shadeGrid[TWK_MAX_LANES];
+  int active = 0;
+  for (int lane = 0; lane < lanes; ++lane)
+  {
+    const LaunchParams q = laneParams(dev, p, lane, lanes, traceGrid);
+    if (q.numPaths <= 0) continue;
+    hipStream_t stream = (lane == 0) ? dev->stream : dev->laneStream[lane];
+    if (lane > 0) HIP_TRY(hipStreamWaitEvent(stream, dev->laneFork, 0));
+    HIP_TRY(hipMemsetAsync(q.counters, 0, sizeof(unsigned int) * TWK_COUNTER_WORDS, stream));
+    // Many more blocks than are resident at once (4 per CU): a block that has finished its windows makes room for the next,
+    // which evens out what the blocks' windows cost. Measured on C2 (shade ms/step): 4 / 8 / 16 / 64 / 256 / 2048 blocks per
+    // CU = 0.310 / 0.309 / 0.305 / 0.294 / 0.290 / 0.298.
+    int grid = (q.numPaths + TWK_SHADE_BLOCK - 1) / TWK_SHADE_BLOCK;
+    if (grid > dev->numCUs * TWK_SHADE_BLOCKS_PER_CU) grid = dev->numCUs * TWK_SHADE_BLOCKS_PER_CU;
+    laneP[active] = q; laneS[active] = stream; shadeGrid[active] = grid; ++active;
+  }
+  for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_GENERATE, laneS[k]); launchGenerate(laneP[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   for (int depth = 0; depth < wavefrontDepth; ++depth)
   {
-    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, depth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
-    timedLaunchBegin(dev, TWK_KERNEL_SHADE); launchShade(p, depth, shadeGrid, dev->stream); timedLaunchEnd(dev);
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], depth, dev->statsEnabled, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_SHADE, laneS[k]); launchShade(laneP[k], depth, shadeGrid[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
   if (maxDepth > 0)
   {
     // closest hits of queue `wavefrontDepth` (empty when wavefrontDepth == maxDepth) + the shadow rays of the last shade
-    timedLaunchBegin(dev, TWK_KERNEL_TRACE); launchTrace(p, wavefrontDepth, dev->statsEnabled, traceGrid, dev->stream); timedLaunchEnd(dev);
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], wavefrontDepth, dev->statsEnabled, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
   if (wavefrontDepth < maxDepth)
   {
-    timedLaunchBegin(dev, TWK_KERNEL_TAIL); launchTail(p, wavefrontDepth, dev->statsEnabled, dev->numCUs * 3, dev->stream); timedLaunchEnd(dev);
+    timedLaunchBegin(dev, TWK_KERNEL_TAIL, laneS[0]); launchTail(laneP[0], wavefrontDepth, dev->statsEnabled, dev->numCUs * 3, laneS[0]); timedLaunchEnd(dev, laneS[0]);
   }
-  timedLaunchBegin(dev, TWK_KERNEL_ACCUM); launchAccumulate(p, dev->stream); timedLaunchEnd(dev);
+  for (int k = 0; k < active; ++k)
+  {
+    if (laneS[k] == dev->stream) continue;
+    const int lane = (int) (std::find(dev->laneStream, dev->laneStream + TWK_MAX_LANES, laneS[k]) - dev->laneStream);
+    HIP_TRY(hipEventRecord(dev->laneDone[lane], laneS[k]));
+    HIP_TRY(hipStreamWaitEvent(dev->stream, dev->laneDone[lane], 0));
+  }
+  // the running mean folds the samples of the pass in iteration order over ALL lanes' paths: after the join, on the handle's stream
+  timedLaunchBegin(dev, TWK_KERNEL_ACCUM, dev->stream); launchAccumulate(p, dev->stream); timedLaunchEnd(dev, dev->stream);
   HIP_TRY(hipGetLastError());
   return TWK_SUCCESS;
 }
@@ -581,6 +665,8 @@ try
   }
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
+  if (const char* e = getenv("TWK_PASS_LANES")) dev->lanesForced = std::max(0, std::min(TWK_MAX_LANES, atoi(e)));
+  if (const char* e = getenv("TWK_LANE_TRACE_WAVES")) dev->laneTraceWaves = std::max(0, atoi(e));
   if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
@@ -610,6 +696,12 @@ try
   freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
   freeDevice(dev->d_pathAlbedo); freeDevice(dev->d_pathNormal); freeDevice(dev->d_aovAlbedo); freeDevice(dev->d_aovNormal);
   dev->builder.release();
+  for (int k = 1; k < TWK_MAX_LANES; ++k)
+  {
+    if (dev->laneStream[k]) (void) hipStreamDestroy(dev->laneStream[k]);
+    if (dev->laneDone[k]) (void) hipEventDestroy(dev->laneDone[k]);
+  }
+  if (dev->laneFork) (void) hipEventDestroy(dev->laneFork);
   if (dev->stream) (void) hipStreamDestroy(dev->stream);
   delete dev;
   return TWK_SUCCESS;
@@ -1437,7 +1529,7 @@ try
     }
   };
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  HIP_TRY(hipMemset(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)));
+  HIP_TRY(hipMemset(dev->d_counters, 0, sizeof(unsigned int) * TWK_COUNTER_WORDS));
   if (numClosest)
   {
     split(closestRays, numClosest);

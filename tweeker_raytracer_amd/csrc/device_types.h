@@ -142,7 +142,7 @@ struct LaunchParams
   const float4*      topNodes;       // TWK_TOP_NODES x 4 float4: the cached top of the tree (device_types.h TWK_NODE_CACHED), built by twk_build
   int                topRoot;        // reference the persistent kernel starts at: TWK_NODE_CACHED | 0, or tlasRoot when the cache is off
   const float4*      wideQ;          // quantised 4-ary nodes, 64 bytes = 4 float4 per inner node index (persistent trace kernel; layout above)
-  const float4*      triangles;      // 3 per triangle slot
+  const float4*      triangles;      // 3 per triangle slot: the vertices, .w of the first = primitive id, of the second = instance (world-space slots)
   const float4*      shadeTriangles; // TWK_SHADE_RECORD (8) per triangle slot, 128 B: geometric normal + the three vertices' normals | tangents | texcoords (bvh_build.hip emitTrianglesKernel)
   const DevInstance* instances;
   const float*       attributes;     // 12 floats per vertex
@@ -204,6 +204,7 @@ struct LaunchParams
   int     numPixels;      // launchWidth * height = launch indices of ONE sample per pixel
   int     numPaths;       // numPixels * batchCount: paths of this wavefront pass, path = sample * numPixels + launch index
   int     batchCount;     // iterations rendered together (iterationIndex .. iterationIndex + batchCount - 1)
+  int     pathBase;       // first path of the pass this launch's streams start at (a pass cut into lanes, device_api.hip renderPass); 0 otherwise
   unsigned int* droppedPushes; // pinned host word (device-mapped): pushes the single-ray traversal could not store (trace_device.h TWK_PUSH); stays 0 on every scene twk_build accepts
 };
 
@@ -227,6 +228,13 @@ struct LaunchParams
 #define TWK_SHADE_BLOCKS_PER_CU 128 // grid of shadeKernel = numCUs x this at most (device_api.hip)
 #ifndef TWK_SHADE_BLOCK
 #define TWK_SHADE_BLOCK       256  // threads per shadeKernel block: queue appends are aggregated per block. Measured (ms/step of shade): 128 → 0.48 (atomics), 256 → 0.33, 512 → 0.34 (waves wait at the block's barriers for its slowest wave), 1024 → 0.37
+#endif
+// Passes of at most this many paths are cut into two lanes (device_api.hip chooseLanes); measured on C2, DESIGN.md 2.
+#ifndef TWK_LANES2_MAX_PATHS
+#define TWK_LANES2_MAX_PATHS 9000000 // batch <= 4 of a 1920x1080 frame
+#endif
+#ifndef TWK_TRACE_SMALL_CHUNK
+#define TWK_TRACE_SMALL_CHUNK 64   // queue slots per chunk of a SHORT queue (fewer than TWK_TRACE_TAIL_MIN long chunks per wave), 0 = round 2's one contiguous share per wave
 #endif
 #ifndef TWK_TRACE_CHUNK
 #define TWK_TRACE_CHUNK       512  // queue slots per chunk of the persistent trace kernel's interleaved assignment (trace_kernels.hip)

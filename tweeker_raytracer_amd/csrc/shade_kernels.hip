@@ -23,8 +23,9 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 {
   const unsigned int index = blockIdx.x * blockDim.x + threadIdx.x;
   if (index >= (unsigned int) p.numPaths) return;
-  const unsigned int sampleIndex = index / (unsigned int) p.numPixels;
-  const unsigned int launchIndex = index - sampleIndex * (unsigned int) p.numPixels;
+  const unsigned int path = index + (unsigned int) p.pathBase; // path of the whole pass; `index` counts within this launch's lane
+  const unsigned int sampleIndex = path / (unsigned int) p.numPixels;
+  const unsigned int launchIndex = path - sampleIndex * (unsigned int) p.numPixels;
   const unsigned int lx = launchIndex % (unsigned int) p.launchWidth;
   const unsigned int ly = launchIndex / (unsigned int) p.launchWidth;
 

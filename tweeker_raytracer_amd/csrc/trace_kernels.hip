@@ -17,6 +17,10 @@
 #include "trace_device.h"
 #include "shade_device.h" // tex2D, rng, tea for the cutout-opacity test
 
+#ifndef TWK_TRI_PAIR
+#define TWK_TRI_PAIR 1 // 1: both triangles of a leaf are fetched before the first is tested; 0: round 2's one fetch + test per loop iteration
+#endif
+
 namespace twk {
 
 // Cutout opacity (anyhit.cu:46-80 radiance, :94-132 shadow): stochastic alpha test of ONE candidate hit. Candidates
@@ -131,13 +135,24 @@ traceKernel(LaunchParams p, int depth)
   const unsigned int numWaves = gridDim.x * (TWK_TRACE_BLOCK / 64);
   const unsigned int waveId   = blockIdx.x * (TWK_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
   unsigned int ticketSize = TWK_TRACE_CHUNK;
+  const bool longQueue = total >= numWaves * ticketSize * TWK_TRACE_TAIL_MIN;
+#if TWK_TRACE_SMALL_CHUNK
+  // A short queue (deep bounces; a pass of one or a few iterations) goes out in chunks of ONE wave-load, all static and
+  // interleaved like the static half of a long one: chunk c belongs to wave c mod numWaves. Round 2 gave every wave one
+  // contiguous share of 16.. rays instead: a launch of 50 k rays then ran 3,200 waves with 16 of 64 lanes filled, six of
+  // them sharing each SIMD's issue slots (so that a 100-step ray took ~1.3 us per step instead of ~0.4), and a launch of
+  // 2 M primary rays gave each wave a fifth of an image row — the waves on the spheres ran three times as long as those
+  // on the walls (203 us for what takes 80 us inside a 64-iteration pass; profiles/r03e_timeline_b1.txt).
+  if (!longQueue) ticketSize = TWK_TRACE_SMALL_CHUNK;
+#else
   if (total < numWaves * ticketSize) ticketSize = min((unsigned int) TWK_TRACE_CHUNK, max(16u, ((total + numWaves - 1u) / numWaves + 15u) & ~15u));
+#endif
   unsigned int nextChunk = waveId * ticketSize;
   if (nextChunk >= total) return; // nothing for this wave
   unsigned int poolBase = 0u, poolCount = 0u;
 #if TWK_TRACE_TAIL_DEN
   unsigned int* ticket = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 2];
-  const unsigned int staticEnd = (total >= numWaves * ticketSize * TWK_TRACE_TAIL_MIN) ? ((total - total / TWK_TRACE_TAIL_DEN) / (numWaves * ticketSize)) * (numWaves * ticketSize) : total;
+  const unsigned int staticEnd = longQueue ? ((total - total / TWK_TRACE_TAIL_DEN) / (numWaves * ticketSize)) * (numWaves * ticketSize) : total;
 #else
   const unsigned int staticEnd = total;
 #endif
@@ -394,6 +409,41 @@ traceKernel(LaunchParams p, int depth)
       // shorten the ray; kernel time -0.9 %, and the visit counts no longer equal the same-BVH host walker's. Not kept.)
       // (Handing a leaf's second triangle to an idle lane through the lane crossbar — 17 ds_bpermute + an LDS pairing table —
       // was built and measured: triangle-test lane occupancy 0.33 -> 0.59, kernel time +23 %. Not kept.)
+#if TWK_TRI_PAIR
+      // The triangle phase waits for its fetches, it is not bound by instruction issue: with the slots stored by component and
+      // the ray's axis permutation folded into per-lane row offsets the test lost 30 % of its vector instructions (18 selects)
+      // and the kernel got 4 % SLOWER (rocprofv3: VALU instructions -4.9 %, wave cycles waiting on memory +21 % — three loads at
+      // per-lane offsets return later than three at base + 0 / 16 / 32; profiles/r03q_*, tools/experiments/). So the lever is
+      // the number of dependent memory round trips: a leaf holds up to two triangles (TWK_MAX_LEAF), and both are requested
+      // before the first is tested — one wait per leaf visit instead of one per triangle.
+      for (int ts = triFirst; ts <= triLast; ts += 2)
+      {
+        const float4* tri = p.triangles + 3 * (size_t) ts;
+        const bool two = ts < triLast;
+        const float4 a0 = tri[0], b0 = tri[1], c0 = tri[2];
+        float4 a1 = a0, b1 = b0, c1 = c0;
+        if (two) { a1 = tri[3]; b1 = tri[4]; c1 = tri[5]; }
+        if (COUNT) ++triCount;
+        TWK_WAVE_STEP(triWaveSteps)
+        {
+          float t, beta, gamma;
+          const bool hit = woopIntersect(woop, ray.o, v3(a0), v3(b0), v3(c0), tmin, t, beta, gamma);
+          const int prim = __float_as_int(a0.w);
+          const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b0.w); // world-space slots carry their instance
+          TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts)
+        }
+        if (two && ts < triLast) // (an any-hit ray that accepted the first triangle has set triLast = -1)
+        {
+          if (COUNT) ++triCount;
+          TWK_WAVE_STEP(triWaveSteps)
+          float t, beta, gamma;
+          const bool hit = woopIntersect(woop, ray.o, v3(a1), v3(b1), v3(c1), tmin, t, beta, gamma);
+          const int prim = __float_as_int(a1.w);
+          const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b1.w);
+          TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts + 1)
+        }
+      }
+#else
       for (int ts = triFirst; ts <= triLast; ++ts)
       {
         const float4* tri = p.triangles + 3 * (size_t) ts;
@@ -406,6 +456,7 @@ traceKernel(LaunchParams p, int depth)
         const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b.w); // world-space slots carry their instance
         TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts)
       }
+#endif
 #undef TWK_MERGE_HIT
       TWK_PHASE_END(3)
 
