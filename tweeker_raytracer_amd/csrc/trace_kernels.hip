@@ -17,10 +17,6 @@
 #include "trace_device.h"
 #include "shade_device.h" // tex2D, rng, tea for the cutout-opacity test
 
-#ifndef TWK_TRI_PAIR
-#define TWK_TRI_PAIR 1 // 1: both triangles of a leaf are fetched before the first is tested; 0: round 2's one fetch + test per loop iteration
-#endif
-
 namespace twk {
 
 // Cutout opacity (anyhit.cu:46-80 radiance, :94-132 shadow): stochastic alpha test of ONE candidate hit. Candidates
@@ -407,43 +403,14 @@ traceKernel(LaunchParams p, int depth)
       // traversal, Aila & Laine 2009) — was built and measured on C2: lane occupancy of this phase 0.33 -> 0.42, of the
       // node step 0.62 -> 0.64, but 3.4 % more node visits and 3 % more triangle tests before the postponed triangles can
       // shorten the ray; kernel time -0.9 %, and the visit counts no longer equal the same-BVH host walker's. Not kept.)
+      // (Round 3, two more builds of this phase, both bit-identical, neither kept: the slots stored BY COMPONENT with the ray's
+      // axis permutation folded into per-lane row offsets — 30 % fewer vector instructions per test (the 18 selects go) —
+      // made the kernel 4 % slower: rocprofv3 counts 4.9 % fewer VALU instructions and 21 % more wave cycles waiting on
+      // memory; three loads at per-lane offsets return later than three at base + 0 / 16 / 32 (the same array read in memory
+      // order and permuted with selects runs at the old speed; profiles/r03q_pmc_*, tools/experiments/). And requesting BOTH
+      // triangles of a leaf before testing the first (one wait per leaf visit instead of two): 0.545 against 0.540 ms/step.)
       // (Handing a leaf's second triangle to an idle lane through the lane crossbar — 17 ds_bpermute + an LDS pairing table —
       // was built and measured: triangle-test lane occupancy 0.33 -> 0.59, kernel time +23 %. Not kept.)
-#if TWK_TRI_PAIR
-      // The triangle phase waits for its fetches, it is not bound by instruction issue: with the slots stored by component and
-      // the ray's axis permutation folded into per-lane row offsets the test lost 30 % of its vector instructions (18 selects)
-      // and the kernel got 4 % SLOWER (rocprofv3: VALU instructions -4.9 %, wave cycles waiting on memory +21 % — three loads at
-      // per-lane offsets return later than three at base + 0 / 16 / 32; profiles/r03q_*, tools/experiments/). So the lever is
-      // the number of dependent memory round trips: a leaf holds up to two triangles (TWK_MAX_LEAF), and both are requested
-      // before the first is tested — one wait per leaf visit instead of one per triangle.
-      for (int ts = triFirst; ts <= triLast; ts += 2)
-      {
-        const float4* tri = p.triangles + 3 * (size_t) ts;
-        const bool two = ts < triLast;
-        const float4 a0 = tri[0], b0 = tri[1], c0 = tri[2];
-        float4 a1 = a0, b1 = b0, c1 = c0;
-        if (two) { a1 = tri[3]; b1 = tri[4]; c1 = tri[5]; }
-        if (COUNT) ++triCount;
-        TWK_WAVE_STEP(triWaveSteps)
-        {
-          float t, beta, gamma;
-          const bool hit = woopIntersect(woop, ray.o, v3(a0), v3(b0), v3(c0), tmin, t, beta, gamma);
-          const int prim = __float_as_int(a0.w);
-          const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b0.w); // world-space slots carry their instance
-          TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts)
-        }
-        if (two && ts < triLast) // (an any-hit ray that accepted the first triangle has set triLast = -1)
-        {
-          if (COUNT) ++triCount;
-          TWK_WAVE_STEP(triWaveSteps)
-          float t, beta, gamma;
-          const bool hit = woopIntersect(woop, ray.o, v3(a1), v3(b1), v3(c1), tmin, t, beta, gamma);
-          const int prim = __float_as_int(a1.w);
-          const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b1.w);
-          TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts + 1)
-        }
-      }
-#else
       for (int ts = triFirst; ts <= triLast; ++ts)
       {
         const float4* tri = p.triangles + 3 * (size_t) ts;
@@ -456,7 +423,6 @@ traceKernel(LaunchParams p, int depth)
         const int triInstance = (TWO_LEVEL && currentInstance >= 0) ? currentInstance : __float_as_int(b.w); // world-space slots carry their instance
         TWK_MERGE_HIT(hit, t, beta, gamma, triInstance, prim, ts)
       }
-#endif
 #undef TWK_MERGE_HIT
       TWK_PHASE_END(3)
 
