@@ -238,8 +238,8 @@ static void refreshParams(TwkDevice dev)
   p.numLights = (int) dev->lights.size();
   p.numMaterials = (int) dev->materials.size();
   p.miss = dev->miss;
-  p.hasCutout = 0;
-  for (const DevMaterial& m : dev->materials) if (m.textureCutout != 0) p.hasCutout = 1;
+  p.hasCutout = 0; p.hasAlbedoTexture = 0;
+  for (const DevMaterial& m : dev->materials) { if (m.textureCutout != 0) p.hasCutout = 1; if (m.textureAlbedo != 0) p.hasAlbedoTexture = 1; }
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)
   {

@@ -160,6 +160,7 @@ struct LaunchParams
   int   numMaterials;   // (the launch parameters are read with scalar loads: their layout shows in the kernels' code)
   int   miss;
   int   hasCutout;      // some material has cutout opacity: trace kernels run the stochastic any-hit candidate loop
+  int   hasAlbedoTexture; // some material multiplies its albedo with the albedo texture: selects the shade kernel variant
   unsigned int envWidth, envHeight;
   float envIntegral, envRotation;
 

@@ -110,8 +110,18 @@ __global__ void __launch_bounds__(256) generateKernel(LaunchParams p)
 // block sums the wave counts through LDS and one lane issues ONE returning atomic per queue per block iteration. With one atomic per
 // wave the two counter words saw ~110 k returning atomics per step and the kernel sat in s_waitcnt for 87 % of its
 // wave-cycles (a single word sustains ~90 atomics/us on this chip: MI355X_MICROARCH "dequeue").
+// Waves per SIMD the register allocation aims at (launch bounds), per kernel variant. The variant without the spherical
+// environment needs 107 VGPRs unconstrained and fits 96 — five waves per SIMD — WITHOUT scratch (the texture variant
+// with 16 bytes of it); the environment variants spill 28 / 72 bytes at 96 and stay at four waves (113 VGPRs, 36 bytes).
+// Measured, whole frame, 4 -> 5 waves: C2 2 439 -> 2 525, C4 geometry 4 173 -> 4 309, C4 instances 3 712 -> 3 757, a C5
+// rank's share 2 253 -> 2 317 Msamples/s; C3 (environment + textures) 3 869 -> 3 764, hence the split. Six waves (80
+// VGPRs) spill 68..136 bytes in every variant. (Round 2 forced 96 registers on the one-for-all kernel: 0.290 -> 0.350 ms
+// per step; what changed is that the variant no longer carries the environment sampler's and the texture fetch's live state.)
 #ifndef TWK_SHADE_WAVES
-#define TWK_SHADE_WAVES 4
+#define TWK_SHADE_WAVES 5
+#endif
+#ifndef TWK_SHADE_WAVES_ENV
+#define TWK_SHADE_WAVES_ENV 4
 #endif
 
 // The streams of one queue slot, as loaded (the fetch is issued one block iteration ahead, see shadeKernel).
@@ -143,7 +153,8 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
 // (s_waitcnt vmcnt(0)), which is exactly what the two barriers of the append must not do: see shadeKernel.
 TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(LaunchParams p, int depth)
+template<bool ENV, bool TEX>
+__global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : TWK_SHADE_WAVES) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
   // of iteration i + 1, so no third barrier per iteration is needed.
@@ -176,7 +187,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, TWK_SHADE_WAVES) shadeKernel(
     {
       out.throughputPdf = in.throughputPdf;
       out.seedFlags     = in.seedFlags;
-      shadePath(p, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
+      shadePath<ENV, TEX>(p, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
       if (p.stats != nullptr) { if (in.instanceIndex < 0) ++statMiss; else ++statHit; }
     }
 
@@ -430,7 +441,12 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 }
 void launchShade(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
-  hipLaunchKernelGGL(shadeKernel, dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
+  const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {
