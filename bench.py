@@ -471,6 +471,33 @@ def main():
             "nodes_per_ray": counts["nodesVisited"] / max(1, n_walk), "triangles_per_ray": counts["trianglesTested"] / max(1, n_walk),
         }
 
+        # ---- the same kernels on one host core: the product's kernel headers compiled by g++ (oracle/host_kernels.cpp), run as
+        # the same wavefront on the device-built scene — north_star's "single-threaded C++ CPU fallback of the same kernels"
+        try:
+            host = orc.HostKernels(dev)
+            host_iterations = 0
+            while host.seconds < args.cpu_seconds * 0.5 and host_iterations < iterations:
+                host.render(host_iterations)
+                host_iterations += 1
+            dev.setLaunchBatch(batch)
+            dev.setOutputDevicePointer(0, 0)
+            probe = twk.Device(ordinal=local_rank, miss=info.miss)   # a fresh accumulation buffer for the same iterations
+            app.initDevice(probe)
+            for it in range(host_iterations):
+                probe.render(it)
+            gpu_same = probe.getOutputBufferHost()
+            probe.close()
+            hc = host.counts
+            result["cpu_baseline"]["same_kernels_one_core"] = {
+                "value": width * height * host_iterations / max(host.seconds, 1e-9) / 1.0e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/host_kernels.cpp (shade_device.h / trace_device.h / device_math.h compiled by g++ -O2 -ffp-contract=off, the wavefront stages on one thread, the device-built BVH): iterations 0..{host_iterations - 1} of the {width}x{height} frame in {host.seconds:.1f} s",
+                "Mrays_per_s": (hc["radianceRays"] + hc["shadowRays"]) / max(host.seconds, 1e-9) / 1.0e6,
+                "nodes_per_ray_binary_traversal": hc["nodesVisited"] / max(1, hc["radianceRays"] + hc["shadowRays"]),
+                "sample_bit_identical_to_gpu": bool(np.array_equal(host.getOutputBufferHost().view(np.uint32), gpu_same.view(np.uint32))),
+            }
+        except Exception as e:  # the checker must not take the measured line down with it
+            result["cpu_baseline"]["same_kernels_one_core"] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     dev.close()

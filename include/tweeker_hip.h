@@ -355,6 +355,14 @@ typedef struct TwkAccelerationInfo
 } TwkAccelerationInfo;
 int twk_debug_read_acceleration(TwkDevice dev, TwkAccelerationInfo* info, void* wideNodes, void* triangles, void* instances);
 
+/* Host copy of everything the kernels read of the scene, for the host build of the kernels (oracle/host_kernels.cpp: the
+ * north_star's "single-threaded C++ CPU fallback of the same kernels", test infrastructure like the oracle): writes the
+ * handle's launch parameters (csrc/device_types.h LaunchParams, `paramsBytes` must equal its size) with every SCENE pointer
+ * (binary nodes, triangle slots, shading records, instances, materials, lights, camera, textures, environment tables)
+ * replaced by a pointer into host memory owned by the handle (valid until the next twk_build / twk_debug_snapshot_scene /
+ * twk_device_destroy); the path streams, counters and output pointers are null. Nothing in the product reads it back. */
+int twk_debug_snapshot_scene(TwkDevice dev, void* launchParams, size_t paramsBytes);
+
 /* Unit taps of the device math used by the shaders (bit-exact parity with the oracle):
  * op 0 sin, 1 cos, 2 exp, 3 atan2(x[i], y[i]), 4 acos, 5 atan, 6 sqrt, 7 1/x, 8 log, 9 pow(x[i], y[i]). */
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n);

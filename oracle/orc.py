@@ -1,6 +1,7 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY. ctypes view of oracle/liboracle.so (CPU restatement of the reference's
 path tracer, see oracle/orc_shaders.h) and of oracle/_ref/libref_host.so (the reference's own host sources
-compiled in the build container). Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+compiled in the build container). Also of oracle/libhostkernels.so: the PRODUCT's kernel headers compiled for the host (host_kernels.cpp), run on a scene a
+Device built. Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
 """
 import ctypes as C
 import os
@@ -194,6 +195,42 @@ class Oracle:
         ids = np.zeros((n, 2), np.int32)
         self._chk(self.lib.orc_trace_rays(self._h, _f(rays), C.c_size_t(n), int(bool(anyHit)), _f(tbg), ids.ctypes.data_as(_ip)))
         return tbg, ids
+
+
+HOST_KERNELS_PATH = os.path.join(_HERE, "libhostkernels.so")
+
+
+class HostKernels:
+    """The product's kernels compiled for the host (oracle/host_kernels.cpp) on the scene a Device built: the
+    north_star's "single-threaded C++ CPU fallback of the same kernels". render() runs ONE wavefront pass of `batch`
+    iterations on the calling thread into the running-mean image it keeps."""
+
+    def __init__(self, device):
+        self.lib = _load(HOST_KERNELS_PATH)
+        self.lib.hostk_params_bytes.restype = C.c_size_t
+        n = self.lib.hostk_params_bytes()
+        self._params = C.create_string_buffer(n)
+        from tweeker_raytracer_amd import _lib as L
+        L.check(L.lib.twk_debug_snapshot_scene(device.handle, self._params, C.c_size_t(n)))
+        self._device = device  # owns the host copies of the scene arrays
+        h, w = device.state.resolution[1], device.launchWidth
+        self.image = np.zeros((h, w, 4), np.float32)
+        self.seconds = 0.0
+        self.counts = {}
+
+    def render(self, firstIteration, batch=1):
+        secs = C.c_double(0.0)
+        counts = (C.c_uint64 * 6)()
+        rc = self.lib.hostk_render(self._params, C.c_size_t(len(self._params)), C.c_uint(int(firstIteration)), int(batch), _f(self.image), C.byref(secs), counts)
+        if rc != 0:
+            raise RuntimeError("hostk_render failed (bad arguments, a scene with cutout opacity, or a dropped stack push)")
+        self.seconds += secs.value
+        names = ("radianceRays", "shadowRays", "nodesVisited", "trianglesTested", "instancesEntered", "shadedSegments")
+        self.counts = {k: self.counts.get(k, 0) + int(counts[i]) for i, k in enumerate(names)}
+        return secs.value
+
+    def getOutputBufferHost(self):
+        return self.image
 
 
 def walk_same_bvh(acceleration, rays, anyHit=False):

@@ -150,6 +150,8 @@ struct TwkDevice_t
   int   lanesForced = 0; // TWK_PASS_LANES: 0 = choose by pass size
   int   laneTraceWaves = 0; // TWK_LANE_TRACE_WAVES: trace blocks per CU of each lane (0 = TWK_TRACE_WAVES / lanes)
 
+  std::vector<std::vector<char>> hostScene; // twk_debug_snapshot_scene: host copies of the scene arrays
+
   LaunchParams params;
   BvhBuilder builder;
 };
@@ -1584,6 +1586,50 @@ try
   return TWK_SUCCESS;
 }
 TWK_CATCH("twk_debug_read_acceleration")
+
+int twk_debug_snapshot_scene(TwkDevice dev, void* launchParams, size_t paramsBytes)
+try
+{
+  int rc = activate(dev, "twk_debug_snapshot_scene"); if (rc) return rc;
+  if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_snapshot_scene: twk_build has not been called");
+  if (!launchParams || paramsBytes != sizeof(LaunchParams)) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_snapshot_scene: paramsBytes must be sizeof(LaunchParams) = " + std::to_string(sizeof(LaunchParams)));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  refreshParams(dev);
+  LaunchParams q = dev->params;
+  dev->hostScene.clear();
+  rc = TWK_SUCCESS;
+  auto host = [&](const void* devicePointer, size_t bytes) -> const void*
+  {
+    if (!devicePointer || bytes == 0) return nullptr;
+    dev->hostScene.emplace_back(bytes);
+    if (hipMemcpy(dev->hostScene.back().data(), devicePointer, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = TWK_ERROR_HIP;
+    return dev->hostScene.back().data();
+  };
+  q.nodes          = static_cast<const BvhNode*>(host(dev->d_nodes, sizeof(BvhNode) * dev->totalNodes));
+  q.wideQ          = static_cast<const float4*>(host(dev->d_wideQ, sizeof(float4) * 4 * dev->totalNodes));
+  q.topNodes       = static_cast<const float4*>(host(dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
+  q.triangles      = static_cast<const float4*>(host(dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles));
+  q.shadeTriangles = static_cast<const float4*>(host(dev->d_shadeTriangles, sizeof(float4) * TWK_SHADE_RECORD * dev->totalTriangles));
+  q.instances      = static_cast<const DevInstance*>(host(dev->d_instances, sizeof(DevInstance) * dev->instances.size()));
+  q.materials      = static_cast<const DevMaterial*>(host(dev->d_materials, sizeof(DevMaterial) * dev->materials.size()));
+  q.lights         = static_cast<const DevLight*>(host(dev->d_lights, sizeof(DevLight) * dev->lights.size()));
+  q.camera         = static_cast<const float*>(host(dev->d_camera, sizeof(float) * 12));
+  q.attributes = nullptr; q.indices = nullptr; // build input only
+  for (int k = 0; k < 3; ++k)
+    q.textures[k].texels = static_cast<const float4*>(host(dev->d_texels[k], sizeof(float4) * (size_t) q.textures[k].width * (size_t) q.textures[k].height));
+  q.envCDF_U = static_cast<const float*>(host(dev->d_envCDF_U, sizeof(float) * ((size_t) q.envWidth + 1) * q.envHeight));
+  q.envCDF_V = static_cast<const float*>(host(dev->d_envCDF_V, sizeof(float) * ((size_t) q.envHeight + 1)));
+  if (rc) return twkSetError(rc, "twk_debug_snapshot_scene: device-to-host copy failed");
+  // streams, counters, outputs: the host build allocates its own
+  for (int k = 0; k < 2; ++k) { q.rayOrg[k] = nullptr; q.rayDir[k] = nullptr; q.rayPixel[k] = nullptr; q.rayThroughput[k] = nullptr; q.raySeedFlags[k] = nullptr; }
+  q.hitRecord = nullptr; q.hitInstance = nullptr; q.shadowOrg = nullptr; q.shadowDir = nullptr; q.shadowPixel = nullptr; q.shadowPending = nullptr;
+  q.pathRadiance = nullptr; q.volumeStack = nullptr; q.pathAlbedo = nullptr; q.pathNormal = nullptr; q.aovAlbedo = nullptr; q.aovNormal = nullptr;
+  q.output = nullptr; q.counters = nullptr; q.stats = nullptr; q.firstHit = nullptr; q.firstHitInstance = nullptr; q.traceStackSpill = nullptr;
+  q.overflowSlots = nullptr; q.droppedPushes = nullptr;
+  memcpy(launchParams, &q, sizeof(q));
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_debug_snapshot_scene")
 
 int twk_debug_math(TwkDevice dev, int op, const float* x, const float* y, float* out, size_t n)
 try

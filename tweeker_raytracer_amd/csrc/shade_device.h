@@ -750,4 +750,141 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   out.nextPos = prd.pos; out.nextDir = prd.wi;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Body of generateKernel for path `index` of the launch (shade_kernels.hip; also what the host build of the kernels runs:
+// oracle/host_kernels.cpp).
+TWK_D void generatePath(const LaunchParams& p, const unsigned int index)
+{
+  const unsigned int path = index + (unsigned int) p.pathBase; // path of the whole pass; `index` counts within this launch's lane
+  const unsigned int sampleIndex = path / (unsigned int) p.numPixels;
+  const unsigned int launchIndex = path - sampleIndex * (unsigned int) p.numPixels;
+  const unsigned int lx = launchIndex % (unsigned int) p.launchWidth;
+  const unsigned int ly = launchIndex / (unsigned int) p.launchWidth;
+
+  unsigned int launchColumn = lx;
+  bool active = true;
+  if (p.distribution && 1 < p.deviceCount)
+  {
+    launchColumn = distribute(p, lx, ly);
+    active = launchColumn < (unsigned int) p.resolution[0];
+  }
+
+  V3 origin = v3(0.0f), direction = v3(0.0f, 0.0f, 1.0f);
+  unsigned int seed = 0;
+  if (active)
+  {
+    seed = tea<4>((unsigned int) p.resolution[0] * ly + launchColumn, p.iterationIndex + sampleIndex);
+
+    const float screenX = float(p.resolution[0]), screenY = float(p.resolution[1]);
+    const float pixelX  = float(launchColumn),    pixelY  = float(ly);
+    const float sampleX = rng(seed);
+    const float sampleY = rng(seed);
+
+    const float* cam = p.camera;
+    const V3 P = v3(cam[0], cam[1], cam[2]), U = v3(cam[3], cam[4], cam[5]), V = v3(cam[6], cam[7], cam[8]), W = v3(cam[9], cam[10], cam[11]);
+
+    if (p.lensShader == 1) // lens_shader.cu:55-73 fisheye
+    {
+      const float fx = pixelX + sampleX, fy = pixelY + sampleY;
+      const float cx = screenX * 0.5f, cy = screenY * 0.5f;
+      const float inv = 1.0f / sqrtf(cx * cx + cy * cy);
+      const float uvx = (fx - cx) * inv, uvy = (fy - cy) * inv;
+      const float z = cosP(sqrtf(uvx * uvx + uvy * uvy) * 0.7071067812f * 0.5f * kPi);
+      const V3 Un = normalize(U), Vn = normalize(V), Wn = normalize(W);
+      origin = P;
+      direction = normalize(uvx * Un + uvy * Vn + z * Wn);
+    }
+    else if (p.lensShader == 2) // lens_shader.cu:76-99 sphere
+    {
+      const float uvx = (pixelX + sampleX) / screenX, uvy = (pixelY + sampleY) / screenY;
+      const float phi   = uvx * 2.0f * kPi;
+      const float theta = uvy * kPi;
+      const float sinTheta = sinP(theta);
+      const V3 v = v3(-sinP(phi) * sinTheta, -cosP(theta), -cosP(phi) * sinTheta);
+      const V3 Un = normalize(U), Vn = normalize(V), Wn = normalize(W);
+      origin = P;
+      direction = normalize(v.x * Un + v.y * Vn + v.z * Wn);
+    }
+    else // lens_shader.cu:40-52 pinhole
+    {
+      const float ndcX = ((pixelX + sampleX) / screenX) * 2.0f - 1.0f;
+      const float ndcY = ((pixelY + sampleY) / screenY) * 2.0f - 1.0f;
+      origin = P;
+      direction = normalize(U * ndcX + V * ndcY + W);
+    }
+  }
+
+  // integrator prologue (raygeneration.cu:53-62): black radiance, unit throughput, empty volume stack
+  p.pathRadiance[index]   = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
+  if (p.pathAlbedo != nullptr)
+  {
+    p.pathAlbedo[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // Optix7Gui raygeneration.cu:66-71: black, null vector
+    p.pathNormal[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  p.rayThroughput[0][index] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+  p.raySeedFlags[0][index]  = make_uint2(seed, 0u);
+
+  // Inactive launch indices (tile columns beyond the image) still own a slot so that queue 0 is the
+  // identity mapping; they carry tmax < tmin and never hit anything, and shade drops them.
+  p.rayOrg[0][index]   = make_float4(origin.x, origin.y, origin.z, p.sceneEpsilon);
+  p.rayDir[0][index]   = make_float4(direction.x, direction.y, direction.z, active ? RT_DEFAULT_MAX : -1.0f);
+  p.rayPixel[0][index] = index;
+  if (index == 0) p.counters[0] = (unsigned int) p.numPaths;
+}
+
+// Body of accumulateKernel for launch index `index` (raygeneration.cu:222-253).
+TWK_D void accumulateLaunchIndex(const LaunchParams& p, const unsigned int index)
+{
+  const bool aov = (p.aovAlbedo != nullptr);
+  // Where this launch index accumulates: its slot of the packed tile buffer (single device, LocalCopy), or — shared
+  // frame of the ZeroCopy / PeerAccess strategies — the pixel it maps to, as __raygen__path_tracer addresses
+  // sysData.outputBuffer (raygeneration.cu:175-183,229): index = y * W + distribute(launch index)
+  size_t outIndex = index;
+  if (p.outputFrame)
+  {
+    const unsigned int lx = index % (unsigned int) p.launchWidth, ly = index / (unsigned int) p.launchWidth;
+    const unsigned int column = (p.distribution && 1 < p.deviceCount) ? distribute(p, lx, ly) : lx;
+    if (column >= (unsigned int) p.resolution[0]) return;
+    outIndex = (size_t) ly * (unsigned int) p.resolution[0] + column;
+  }
+  float4 dst = p.output[outIndex];
+  float4 dstAlbedo = aov ? p.aovAlbedo[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 dstNormal = aov ? p.aovNormal[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  bool touched = false;
+  for (int s = 0; s < p.batchCount; ++s)
+  {
+    const size_t path = (size_t) s * p.numPixels + index;
+    const float4 r = p.pathRadiance[path];
+    if (r.w == 0.0f) continue; // launch index outside the image (tile padding): never written, like the early return at raygeneration.cu:180-183
+    V3 radiance = v3(r.x, r.y, r.z);
+    if (!(isnan(radiance.x) || isnan(radiance.y) || isnan(radiance.z)))
+    {
+      const unsigned int iteration = p.iterationIndex + (unsigned int) s;
+      V3 albedo = v3(0.0f), normal = v3(0.0f);
+      if (aov) { albedo = v3(p.pathAlbedo[path]); normal = v3(p.pathNormal[path]); }
+      if (0 < iteration)
+      {
+        const float t = 1.0f / float(iteration + 1);
+        radiance = lerp(v3(dst.x, dst.y, dst.z), radiance, t);
+        if (aov)
+        {
+          // Optix7Gui raygeneration.cu:243-252: same running mean; the mean normal is renormalised unless it vanished
+          albedo = lerp(v3(dstAlbedo), albedo, t);
+          normal = lerp(v3(dstNormal), normal, t);
+          if (isNotNull(normal)) normal = normalize(normal);
+        }
+      }
+      dst = make_float4(radiance.x, radiance.y, radiance.z, 1.0f);
+      dstAlbedo = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
+      dstNormal = make_float4(normal.x, normal.y, normal.z, 0.0f);
+      touched = true;
+    }
+  }
+  if (touched)
+  {
+    p.output[outIndex] = dst;
+    if (aov) { p.aovAlbedo[index] = dstAlbedo; p.aovNormal[index] = dstNormal; }
+  }
+}
+
 } // namespace twk
