@@ -68,7 +68,9 @@ private:
   int  m_sahCapacity = 0;
   int* m_sahOrder[2] = {nullptr, nullptr}; int* m_sahSlot[2] = {nullptr, nullptr};
   void* m_sahActive[2] = {nullptr, nullptr}; void* m_sahSmall = nullptr; void* m_sahSplit = nullptr;
-  unsigned int* m_sahCb = nullptr; unsigned int* m_sahBins = nullptr; unsigned int* m_sahFill = nullptr;
+  unsigned int* m_sahCb = nullptr; unsigned int* m_sahBins = nullptr;
+  int* m_sahFlags = nullptr; int* m_sahPrefix = nullptr; void* m_sahChildCounts = nullptr; void* m_sahChildOffsets = nullptr;
+  void* m_sahScanTemp = nullptr; size_t m_sahScanBytes = 0;
   int* m_sahCounters = nullptr; double* m_sahCost = nullptr;
   double m_lastSahInner = 0.0, m_lastSahLeaf = 0.0;
   int    m_lastHeight = 0;

@@ -8,9 +8,15 @@
 // LARGE nodes (more than SAH_SMALL primitives):
 //   bounds    centroid bounds per node                       (atomic min / max, wave-aggregated when a wave is in one node)
 //   bin       16 bins per axis: primitive count + box        (atomics)
-//   select    one thread per node: sweep the 3 x 15 split planes, cost = area(L) n(L) + area(R) n(R); allocate the
-//             children (inner-node indices from one counter; a full binary tree over n leaves has n - 1 of them)
-//   partition primitives move to their side of the split inside the node's range
+//   select    one thread per node: sweep the 3 x 15 split planes, cost = area(L) n(L) + area(R) n(R), and say what each
+//             child will be (leaf / small / large)
+//   assign    exclusive scan of the per-node child counts, then one thread per node gives its children their inner-node
+//             indices (a full binary tree over n leaves has n - 1 of them) and their slots in the next level's lists
+//   partition a STABLE partition inside the node's range: exclusive scan of the "goes left" flags over all positions,
+//             rank = prefix(position) - prefix(first position of the node)
+// No atomic decides an index or a position (round 2 ranked primitives with atomics on a fill counter and took node
+// indices from an atomic counter: topology, slot order, visit counts and the LDS top-of-tree cache then differed from
+// run to run — the hit records never did): the same input gives the same tree, bit for bit (test_gpu_edge_cases.py).
 // Nodes of at most SAH_SMALL primitives are finished by ONE thread each with an exact sweep over all three axes
 // (insertion sort of <= 8 centroids), which removes the bottom levels — most of the nodes — from the level loop.
 // The tree goes down to single primitives like the radix tree does; the refit collapses subtrees of <= maxLeaf
@@ -19,6 +25,8 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 namespace twk {
 
@@ -28,6 +36,9 @@ namespace twk {
 
 struct SahActive { int node, first, count, pad; };
 struct SahSplit  { int axis, bin, leftCount, first, slotL, slotR, pad0, pad1; };
+// children a split creates: inner nodes, entries of the next level's active list (large), entries of the small list
+struct SahCounts { int inner, large, small, pad; };
+struct SahCountsPlus { TWK_HD SahCounts operator()(const SahCounts& a, const SahCounts& b) const { SahCounts r; r.inner = a.inner + b.inner; r.large = a.large + b.large; r.small = a.small + b.small; r.pad = 0; return r; } };
 
 TWK_D unsigned int sahOrdered(float f)
 {
@@ -59,21 +70,20 @@ __global__ void sahInitKernel(int count, int* __restrict__ order, int* __restric
   slotOf[i] = large ? 0 : -1;
 }
 
-// cb: 6 words per active node (min xyz, max xyz as ordered uints); bins: 3 * SAH_BINS * SAH_BIN_WORDS words; fill: 2 words.
-__global__ void sahClearKernel(int numActive, unsigned int* __restrict__ cb, unsigned int* __restrict__ bins, unsigned int* __restrict__ fill)
+// cb: 6 words per active node (min xyz, max xyz as ordered uints); bins: 3 * SAH_BINS * SAH_BIN_WORDS words.
+__global__ void sahClearKernel(int numActive, unsigned int* __restrict__ cb, unsigned int* __restrict__ bins)
 {
-  const int perNode = 6 + 3 * SAH_BINS * SAH_BIN_WORDS + 2;
+  const int perNode = 6 + 3 * SAH_BINS * SAH_BIN_WORDS;
   const long long total = (long long) numActive * perNode;
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
   {
     const int k = (int) (i / perNode), w = (int) (i % perNode);
     if (w < 6) cb[6 * (size_t) k + w] = (w < 3) ? 0xffffffffu : 0u;
-    else if (w < 6 + 3 * SAH_BINS * SAH_BIN_WORDS)
+    else
     {
       const int b = w - 6, word = b % SAH_BIN_WORDS;
       bins[(size_t) k * 3 * SAH_BINS * SAH_BIN_WORDS + b] = (word == 0) ? 0u : ((word < 4) ? 0xffffffffu : 0u);
     }
-    else fill[2 * (size_t) k + (w - 6 - 3 * SAH_BINS * SAH_BIN_WORDS)] = 0u;
   }
 }
 
@@ -165,26 +175,12 @@ __global__ void __launch_bounds__(256) sahBinKernel(int count, const int* __rest
   }
 }
 
-// Registers a child range: a leaf reference for one primitive, else a fresh inner node that goes to the small list
-// (finished by sahSmallKernel) or to the next level's active list. Returns the child reference; slot = active slot or -1.
-TWK_D int sahMakeChild(int parent, int first, int count, int* nodeCounter, int* innerParent, int* leafParent, int2* range,
-                       SahActive* nextActive, int* nextCount, SahActive* smallList, int* smallCount, int& slot)
-{
-  slot = -1;
-  if (count == 1) { leafParent[first] = parent; return ~first; }
-  const int c = atomicAdd(nodeCounter, 1);
-  innerParent[c] = parent;
-  range[c] = make_int2(first, count);
-  SahActive a; a.node = c; a.first = first; a.count = count; a.pad = 0;
-  if (count <= SAH_SMALL) smallList[atomicAdd(smallCount, 1)] = a;
-  else { slot = atomicAdd(nextCount, 1); nextActive[slot] = a; }
-  return c;
-}
+// What a child range becomes: 0 a leaf reference (one primitive), 1 an inner node finished by sahSmallKernel, 2 an inner
+// node split again on the next level.
+TWK_D int sahChildKind(int count) { return (count == 1) ? 0 : ((count <= SAH_SMALL) ? 1 : 2); }
 
 __global__ void sahSelectKernel(int numActive, const SahActive* __restrict__ active, const unsigned int* __restrict__ bins, int forceMiddle,
-                                SahSplit* __restrict__ split, int* nodeCounter, int* __restrict__ left, int* __restrict__ right,
-                                int* __restrict__ innerParent, int* __restrict__ leafParent, int2* __restrict__ range,
-                                SahActive* __restrict__ nextActive, int* nextCount, SahActive* __restrict__ smallList, int* smallCount)
+                                SahSplit* __restrict__ split, SahCounts* __restrict__ childCounts)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= numActive) return;
@@ -234,16 +230,87 @@ __global__ void sahSelectKernel(int numActive, const SahActive* __restrict__ act
   if (bestAxis < 0) { bestBin = -1; bestLeft = a.count / 2; } // all centroids in one bin on every axis (or a forced level): cut the range in the middle
 
   SahSplit sp;
-  sp.axis = bestAxis; sp.bin = bestBin; sp.leftCount = bestLeft; sp.first = a.first; sp.pad0 = sp.pad1 = 0;
-  const int l = sahMakeChild(a.node, a.first, bestLeft, nodeCounter, innerParent, leafParent, range, nextActive, nextCount, smallList, smallCount, sp.slotL);
-  const int r = sahMakeChild(a.node, a.first + bestLeft, a.count - bestLeft, nodeCounter, innerParent, leafParent, range, nextActive, nextCount, smallList, smallCount, sp.slotR);
-  left[a.node] = l; right[a.node] = r;
+  sp.axis = bestAxis; sp.bin = bestBin; sp.leftCount = bestLeft; sp.first = a.first; sp.slotL = -1; sp.slotR = -1; sp.pad0 = sp.pad1 = 0;
+  split[k] = sp;
+  const int kindL = sahChildKind(bestLeft), kindR = sahChildKind(a.count - bestLeft);
+  SahCounts c;
+  c.inner = (kindL != 0) + (kindR != 0); c.large = (kindL == 2) + (kindR == 2); c.small = (kindL == 1) + (kindR == 1); c.pad = 0;
+  childCounts[k] = c;
+}
+
+// One thread per active node, after the exclusive scan of childCounts: its children get their inner-node indices and their
+// slots in the next level's active list / the small list — left child first — from the scanned offsets, i.e. from the
+// node's position in the (deterministic) active list and nothing else. counters: [0] inner nodes allocated so far,
+// [1] small nodes so far (both as of the START of this level; sahAdvanceKernel moves them on).
+__global__ void sahAssignKernel(int numActive, const SahActive* __restrict__ active, SahSplit* __restrict__ split, const SahCounts* __restrict__ offsets,
+                                const int* __restrict__ counters, int* __restrict__ left, int* __restrict__ right,
+                                int* __restrict__ innerParent, int* __restrict__ leafParent, int2* __restrict__ range,
+                                SahActive* __restrict__ nextActive, SahActive* __restrict__ smallList)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= numActive) return;
+  const SahActive a = active[k];
+  SahSplit sp = split[k];
+  const SahCounts off = offsets[k];
+  int inner = counters[0] + off.inner, large = off.large, small = counters[1] + off.small;
+  int refs[2];
+  const int childFirst[2] = {a.first, a.first + sp.leftCount}, childCount[2] = {sp.leftCount, a.count - sp.leftCount};
+  int slots[2] = {-1, -1};
+  for (int side = 0; side < 2; ++side)
+  {
+    const int kind = sahChildKind(childCount[side]);
+    if (kind == 0) { leafParent[childFirst[side]] = a.node; refs[side] = ~childFirst[side]; continue; }
+    const int c = inner++;
+    innerParent[c] = a.node;
+    range[c] = make_int2(childFirst[side], childCount[side]);
+    SahActive child; child.node = c; child.first = childFirst[side]; child.count = childCount[side]; child.pad = 0;
+    if (kind == 1) smallList[small++] = child;
+    else { slots[side] = large; nextActive[large++] = child; }
+    refs[side] = c;
+  }
+  left[a.node] = refs[0]; right[a.node] = refs[1];
+  sp.slotL = slots[0]; sp.slotR = slots[1];
   split[k] = sp;
 }
 
+// Moves the running totals on by this level's sums (last offset + last count) and leaves the next level's active count
+// where the host reads it. counters: [0] inner nodes, [1] small nodes, [2] next level's active count.
+__global__ void sahAdvanceKernel(int numActive, const SahCounts* __restrict__ childCounts, const SahCounts* __restrict__ offsets, int* counters)
+{
+  const SahCounts c = childCounts[numActive - 1], o = offsets[numActive - 1];
+  counters[0] += o.inner + c.inner;
+  counters[1] += o.small + c.small;
+  counters[2] = o.large + c.large;
+}
+
+// "Goes to the left child" per position (0 for positions outside every active node): the input of the partition's scan.
+__global__ void sahFlagKernel(int count, const int* __restrict__ order, const int* __restrict__ slotOf,
+                              const float4* __restrict__ primLo, const float4* __restrict__ primHi,
+                              const unsigned int* __restrict__ cb, const SahSplit* __restrict__ split, int* __restrict__ flags)
+{
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= count) return;
+  const int k = slotOf[pos];
+  int toLeft = 0;
+  if (k >= 0)
+  {
+    const SahSplit sp = split[k];
+    if (sp.bin < 0) toLeft = (pos - sp.first) < sp.leftCount; // positional cut
+    else
+    {
+      const int prim = order[pos];
+      const V3 c = sahCentroid(primLo[prim], primHi[prim]);
+      const float cc = (sp.axis == 0) ? c.x : ((sp.axis == 1) ? c.y : c.z);
+      const unsigned int* w = cb + 6 * (size_t) k;
+      toLeft = sahBin(cc, sahFromOrdered(w[sp.axis]), sahFromOrdered(w[3 + sp.axis])) < sp.bin;
+    }
+  }
+  flags[pos] = toLeft;
+}
+
+// Stable partition: a primitive keeps its order among the primitives that go the same way. prefix = exclusive scan of flags.
 __global__ void sahPartitionKernel(int count, const int* __restrict__ order, const int* __restrict__ slotOf,
-                                   const float4* __restrict__ primLo, const float4* __restrict__ primHi,
-                                   const unsigned int* __restrict__ cb, const SahSplit* __restrict__ split, unsigned int* __restrict__ fill,
+                                   const SahSplit* __restrict__ split, const int* __restrict__ flags, const int* __restrict__ prefix,
                                    int* __restrict__ orderNext, int* __restrict__ slotNext)
 {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,48 +319,30 @@ __global__ void sahPartitionKernel(int count, const int* __restrict__ order, con
   const int prim = order[pos];
   if (k < 0) { orderNext[pos] = prim; slotNext[pos] = -1; return; } // finished range: stays where it is
   const SahSplit sp = split[k];
-  bool toLeft;
-  int target;
-  if (sp.bin < 0)
-  {
-    toLeft = (pos - sp.first) < sp.leftCount; // positional cut, nothing moves
-    target = pos;
-  }
-  else
-  {
-    const V3 c = sahCentroid(primLo[prim], primHi[prim]);
-    const float cc = (sp.axis == 0) ? c.x : ((sp.axis == 1) ? c.y : c.z);
-    const unsigned int* w = cb + 6 * (size_t) k;
-    toLeft = sahBin(cc, sahFromOrdered(w[sp.axis]), sahFromOrdered(w[3 + sp.axis])) < sp.bin;
-    // one atomic per wave and side when the whole wave sits in one node (every wave of the top levels), else one per lane
-    const unsigned long long active = __ballot(true);
-    const int k0 = __builtin_amdgcn_readfirstlane(k);
-    unsigned int rank;
-    if (__ballot(k != k0) == 0ull)
-    {
-      const unsigned long long leftMask = __ballot(toLeft), mine = toLeft ? leftMask : (active & ~leftMask);
-      const unsigned int lane = threadIdx.x & 63u;
-      const int leader = __ffsll((long long) mine) - 1;
-      unsigned int base = 0u;
-      if ((int) lane == leader) base = atomicAdd(&fill[2 * (size_t) k + (toLeft ? 0 : 1)], (unsigned int) __popcll(mine));
-      base = __shfl(base, leader);
-      rank = base + (unsigned int) __popcll(mine & ((1ull << lane) - 1ull));
-    }
-    else rank = atomicAdd(&fill[2 * (size_t) k + (toLeft ? 0 : 1)], 1u);
-    target = sp.first + (toLeft ? 0 : sp.leftCount) + (int) rank;
-  }
+  const bool toLeft = flags[pos] != 0;
+  const int leftBefore = prefix[pos] - prefix[sp.first];         // primitives of this node before `pos` that go left
+  const int target = toLeft ? sp.first + leftBefore : sp.first + sp.leftCount + (pos - sp.first - leftBefore);
   orderNext[target] = prim;
   slotNext[target] = toLeft ? sp.slotL : sp.slotR;
 }
 
 // One thread finishes a node of 2..SAH_SMALL primitives: exact SAH sweep over the three axes at every split.
+// A node of c primitives has c - 1 inner nodes below and including itself, so it creates c - 2 new ones: the exclusive
+// scan of (count - 2) over the small list gives every thread the first index of a block of its own.
+__global__ void sahSmallNeedKernel(int numSmall, const SahActive* __restrict__ smallList, int* __restrict__ need)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < numSmall) need[t] = smallList[t].count - 2;
+}
+
 __global__ void sahSmallKernel(int numSmall, const SahActive* __restrict__ smallList, int* __restrict__ order,
                                const float4* __restrict__ primLo, const float4* __restrict__ primHi,
-                               int* nodeCounter, int* __restrict__ left, int* __restrict__ right,
+                               const int* __restrict__ counters, const int* __restrict__ nodeBase, int* __restrict__ left, int* __restrict__ right,
                                int* __restrict__ innerParent, int* __restrict__ leafParent, int2* __restrict__ range)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= numSmall) return;
+  int nextNode = counters[0] + nodeBase[t]; // inner nodes allocated by the level loop + this thread's block
   int stackNode[SAH_SMALL], stackFirst[SAH_SMALL], stackCount[SAH_SMALL];
   int sp = 0;
   stackNode[0] = smallList[t].node; stackFirst[0] = smallList[t].first; stackCount[0] = smallList[t].count; sp = 1;
@@ -354,7 +403,7 @@ __global__ void sahSmallKernel(int numSmall, const SahActive* __restrict__ small
       if (childCount[side] == 1) { leafParent[childFirst[side]] = node; refs[side] = ~childFirst[side]; }
       else
       {
-        const int c = atomicAdd(nodeCounter, 1);
+        const int c = nextNode++;
         innerParent[c] = node;
         range[c] = make_int2(childFirst[side], childCount[side]);
         refs[side] = c;
@@ -371,16 +420,15 @@ __global__ void sahKeysKernel(int count, const int* __restrict__ order, unsigned
   if (i < count) keys[i] = (unsigned long long) (unsigned int) order[i];
 }
 
-__global__ void sahRootKernel(int count, int* nodeCounter, int* innerParent, int2* range, SahActive* active, SahActive* smallList, int* counts)
+__global__ void sahRootKernel(int count, int* innerParent, int2* range, SahActive* active, SahActive* smallList, int* counters)
 {
-  // counts: [0] active count of level 0, [1] next level's count, [2] small count
+  // counters: [0] inner nodes allocated, [1] small nodes, [2] next level's active count
   innerParent[0] = -1;
   range[0] = make_int2(0, count);
-  *nodeCounter = 1;
   SahActive a; a.node = 0; a.first = 0; a.count = count; a.pad = 0;
-  counts[0] = 0; counts[1] = 0; counts[2] = 0;
-  if (count <= SAH_SMALL) { smallList[0] = a; counts[2] = 1; }
-  else { active[0] = a; counts[0] = 1; }
+  counters[0] = 1; counters[1] = 0; counters[2] = 0;
+  if (count <= SAH_SMALL) { smallList[0] = a; counters[1] = 1; }
+  else active[0] = a;
 }
 
 // SAH cost of the tree the refit produced (measurement): sum over the nodes that survive the leaf collapse of
@@ -425,7 +473,16 @@ hipError_t BvhBuilder::reserveSah(int count)
   SAH_CHECK(hipMalloc(&m_sahSplit, sizeof(SahSplit) * maxLarge));
   SAH_CHECK(hipMalloc(&m_sahCb, sizeof(unsigned int) * 6 * maxLarge));
   SAH_CHECK(hipMalloc(&m_sahBins, sizeof(unsigned int) * 3 * SAH_BINS * SAH_BIN_WORDS * maxLarge));
-  SAH_CHECK(hipMalloc(&m_sahFill, sizeof(unsigned int) * 2 * maxLarge));
+  // scans: "goes left" flags and their prefix over the positions (also reused for the small list's node blocks: maxSmall <= n),
+  // child counts and their prefix over the active nodes
+  SAH_CHECK(hipMalloc(&m_sahFlags, sizeof(int) * (n + 64))); SAH_CHECK(hipMalloc(&m_sahPrefix, sizeof(int) * (n + 64)));
+  SAH_CHECK(hipMalloc(&m_sahChildCounts, sizeof(SahCounts) * maxLarge)); SAH_CHECK(hipMalloc(&m_sahChildOffsets, sizeof(SahCounts) * maxLarge));
+  size_t bytesInt = 0, bytesCounts = 0;
+  SAH_CHECK(rocprim::exclusive_scan(nullptr, bytesInt, m_sahFlags, m_sahPrefix, 0, n, rocprim::plus<int>(), (hipStream_t) 0));
+  SAH_CHECK(rocprim::exclusive_scan(nullptr, bytesCounts, static_cast<SahCounts*>(m_sahChildCounts), static_cast<SahCounts*>(m_sahChildOffsets),
+                                    SahCounts{0, 0, 0, 0}, maxLarge, SahCountsPlus(), (hipStream_t) 0));
+  m_sahScanBytes = std::max(bytesInt, bytesCounts);
+  SAH_CHECK(hipMalloc(&m_sahScanTemp, m_sahScanBytes > 0 ? m_sahScanBytes : 16));
   SAH_CHECK(hipMalloc(&m_sahCounters, sizeof(int) * 8));
   SAH_CHECK(hipMalloc(&m_sahCost, sizeof(double) * 2));
   m_sahCapacity = count;
@@ -434,11 +491,13 @@ hipError_t BvhBuilder::reserveSah(int count)
 
 void BvhBuilder::releaseSah()
 {
-  void* p[] = { m_sahOrder[0], m_sahOrder[1], m_sahSlot[0], m_sahSlot[1], m_sahActive[0], m_sahActive[1], m_sahSmall, m_sahSplit, m_sahCb, m_sahBins, m_sahFill, m_sahCounters, m_sahCost };
+  void* p[] = { m_sahOrder[0], m_sahOrder[1], m_sahSlot[0], m_sahSlot[1], m_sahActive[0], m_sahActive[1], m_sahSmall, m_sahSplit, m_sahCb, m_sahBins,
+                m_sahFlags, m_sahPrefix, m_sahChildCounts, m_sahChildOffsets, m_sahScanTemp, m_sahCounters, m_sahCost };
   for (void* q : p) if (q) (void) hipFree(q);
   m_sahOrder[0] = m_sahOrder[1] = m_sahSlot[0] = m_sahSlot[1] = nullptr;
   m_sahActive[0] = m_sahActive[1] = nullptr; m_sahSmall = nullptr; m_sahSplit = nullptr;
-  m_sahCb = m_sahBins = m_sahFill = nullptr; m_sahCounters = nullptr; m_sahCost = nullptr;
+  m_sahCb = m_sahBins = nullptr; m_sahFlags = m_sahPrefix = nullptr; m_sahChildCounts = m_sahChildOffsets = nullptr; m_sahScanTemp = nullptr; m_sahScanBytes = 0;
+  m_sahCounters = nullptr; m_sahCost = nullptr;
   m_sahCapacity = 0;
 }
 
@@ -451,9 +510,10 @@ hipError_t BvhBuilder::buildSahTopology(hipStream_t stream, int count)
   SahActive* active[2] = { static_cast<SahActive*>(m_sahActive[0]), static_cast<SahActive*>(m_sahActive[1]) };
   SahActive* smallList = static_cast<SahActive*>(m_sahSmall);
   SahSplit* split = static_cast<SahSplit*>(m_sahSplit);
-  int* nodeCounter = m_sahCounters + 4;
-  // counters: [0] current level's active count, [1] next level's, [2] small nodes, [4] inner nodes allocated
-  hipLaunchKernelGGL(sahRootKernel, dim3(1), dim3(1), 0, stream, count, nodeCounter, m_innerParent, m_range, active[0], smallList, m_sahCounters);
+  SahCounts* childCounts = static_cast<SahCounts*>(m_sahChildCounts);
+  SahCounts* childOffsets = static_cast<SahCounts*>(m_sahChildOffsets);
+  // counters: [0] inner nodes allocated, [1] small nodes, [2] next level's active count
+  hipLaunchKernelGGL(sahRootKernel, dim3(1), dim3(1), 0, stream, count, m_innerParent, m_range, active[0], smallList, m_sahCounters);
   hipLaunchKernelGGL(sahInitKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[0], m_sahSlot[0], count > SAH_SMALL ? 1 : 0);
   int cur = 0;
   int numActive = (count > SAH_SMALL) ? 1 : 0;
@@ -465,29 +525,42 @@ hipError_t BvhBuilder::buildSahTopology(hipStream_t stream, int count)
     // within log2(count) further levels. (Scenes of millions of triangles finish their SAH levels in 25-35.) twk_build
     // measures the height that results and refuses a scene whose top + bottom height exceeds the stack capacity.
     const int forceMiddle = (level >= 40) ? 1 : 0;
-    const long long clearWords = (long long) numActive * (6 + 3 * SAH_BINS * SAH_BIN_WORDS + 2); // 344 words per node: beyond int at ~6.2 M active nodes
-    hipLaunchKernelGGL(sahClearKernel, dim3((unsigned int) std::min<long long>(4096, (clearWords + 255) / 256)), dim3(256), 0, stream, numActive, m_sahCb, m_sahBins, m_sahFill);
+    const long long clearWords = (long long) numActive * (6 + 3 * SAH_BINS * SAH_BIN_WORDS); // 342 words per node: beyond int at ~6.2 M active nodes
+    const int nodeGrid = (numActive + 63) / 64;
+    hipLaunchKernelGGL(sahClearKernel, dim3((unsigned int) std::min<long long>(4096, (clearWords + 255) / 256)), dim3(256), 0, stream, numActive, m_sahCb, m_sahBins);
     hipLaunchKernelGGL(sahBoundsKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb);
     hipLaunchKernelGGL(sahBinKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb, m_sahBins);
-    hipLaunchKernelGGL(sahSelectKernel, dim3((numActive + 63) / 64), dim3(64), 0, stream, numActive, active[cur], m_sahBins, forceMiddle, split, nodeCounter,
-                       m_left, m_right, m_innerParent, m_leafParent, m_range, active[next], m_sahCounters + 1, smallList, m_sahCounters + 2);
-    hipLaunchKernelGGL(sahPartitionKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb, split, m_sahFill,
+    hipLaunchKernelGGL(sahSelectKernel, dim3(nodeGrid), dim3(64), 0, stream, numActive, active[cur], m_sahBins, forceMiddle, split, childCounts);
+    size_t bytes = m_sahScanBytes;
+    SAH_CHECK(rocprim::exclusive_scan(m_sahScanTemp, bytes, childCounts, childOffsets, SahCounts{0, 0, 0, 0}, (size_t) numActive, SahCountsPlus(), stream));
+    hipLaunchKernelGGL(sahAssignKernel, dim3(nodeGrid), dim3(64), 0, stream, numActive, active[cur], split, childOffsets, m_sahCounters,
+                       m_left, m_right, m_innerParent, m_leafParent, m_range, active[next], smallList);
+    hipLaunchKernelGGL(sahAdvanceKernel, dim3(1), dim3(1), 0, stream, numActive, childCounts, childOffsets, m_sahCounters);
+    hipLaunchKernelGGL(sahFlagKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], m_primLo, m_primHi, m_sahCb, split, m_sahFlags);
+    bytes = m_sahScanBytes;
+    SAH_CHECK(rocprim::exclusive_scan(m_sahScanTemp, bytes, m_sahFlags, m_sahPrefix, 0, (size_t) count, rocprim::plus<int>(), stream));
+    hipLaunchKernelGGL(sahPartitionKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_sahSlot[cur], split, m_sahFlags, m_sahPrefix,
                        m_sahOrder[next], m_sahSlot[next]);
     SAH_CHECK(hipGetLastError());
     int nextCount = 0;
-    SAH_CHECK(hipMemcpyAsync(&nextCount, m_sahCounters + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
-    SAH_CHECK(hipMemsetAsync(m_sahCounters + 1, 0, sizeof(int), stream));
+    SAH_CHECK(hipMemcpyAsync(&nextCount, m_sahCounters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
     SAH_CHECK(hipStreamSynchronize(stream));
     numActive = nextCount;
     cur = next;
   }
   if (numActive > 0) return hipErrorUnknown; // cannot happen: forced halving ends every range within 32 further levels
   int numSmall = 0;
-  SAH_CHECK(hipMemcpyAsync(&numSmall, m_sahCounters + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
+  SAH_CHECK(hipMemcpyAsync(&numSmall, m_sahCounters + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
   SAH_CHECK(hipStreamSynchronize(stream));
   if (numSmall > 0)
-    hipLaunchKernelGGL(sahSmallKernel, dim3((numSmall + 63) / 64), dim3(64), 0, stream, numSmall, smallList, m_sahOrder[cur], m_primLo, m_primHi,
-                       nodeCounter, m_left, m_right, m_innerParent, m_leafParent, m_range);
+  {
+    const int smallGrid = (numSmall + 63) / 64;
+    hipLaunchKernelGGL(sahSmallNeedKernel, dim3(smallGrid), dim3(64), 0, stream, numSmall, smallList, m_sahFlags);
+    size_t bytes = m_sahScanBytes;
+    SAH_CHECK(rocprim::exclusive_scan(m_sahScanTemp, bytes, m_sahFlags, m_sahPrefix, 0, (size_t) numSmall, rocprim::plus<int>(), stream));
+    hipLaunchKernelGGL(sahSmallKernel, dim3(smallGrid), dim3(64), 0, stream, numSmall, smallList, m_sahOrder[cur], m_primLo, m_primHi,
+                       m_sahCounters, m_sahPrefix, m_left, m_right, m_innerParent, m_leafParent, m_range);
+  }
   hipLaunchKernelGGL(sahKeysKernel, dim3(grid), dim3(block), 0, stream, count, m_sahOrder[cur], m_keysOut);
   return hipGetLastError();
 }
