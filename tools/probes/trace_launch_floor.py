@@ -1,8 +1,9 @@
+"""usage (GPU box): rocprofv3 --kernel-trace --output-format csv -d out -o kt -- python3 tools/probes/trace_launch_floor.py; python3 tools/probes/trace_launch_floor_report.py out/.../kt_kernel_trace.csv
 """Duration of ONE persistent trace launch against the number of rays in its queue (twk_debug_trace_queue), under rocprofv3 --kernel-trace:
 rays that miss the scene at once (launch overhead) and random rays inside the Cornell box (longest-ray latency)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/probes/ -> repository root
 sys.path.insert(0, ROOT)
 import tweeker_raytracer_amd as twk
 app = twk.Application(os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box.txt"), os.path.join(ROOT, "scenes", "scene_rtigo3_cornell_box.txt"))
