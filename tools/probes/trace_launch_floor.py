@@ -1,6 +1,7 @@
-"""usage (GPU box): rocprofv3 --kernel-trace --output-format csv -d out -o kt -- python3 tools/probes/trace_launch_floor.py; python3 tools/probes/trace_launch_floor_report.py out/.../kt_kernel_trace.csv
 """Duration of ONE persistent trace launch against the number of rays in its queue (twk_debug_trace_queue), under rocprofv3 --kernel-trace:
-rays that miss the scene at once (launch overhead) and random rays inside the Cornell box (longest-ray latency)."""
+rays that miss the scene at once (launch overhead) and random rays inside the Cornell box (longest-ray latency).
+usage (GPU box): rocprofv3 --kernel-trace --output-format csv -d out -o kt -- python3 tools/probes/trace_launch_floor.py
+                 python3 tools/probes/trace_launch_floor_report.py out/.../kt_kernel_trace.csv"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/probes/ -> repository root
