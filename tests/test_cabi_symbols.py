@@ -72,3 +72,23 @@ def test_every_entry_point_is_a_function_try_block():
             assert m.group(1) in cannot_throw, f"{rel}: {m.group(1)} is defined without a try block"
     declared = set(_header_functions()) - {"twk_last_error"}
     assert declared <= seen, declared - seen
+
+
+def test_bench_carries_pmc_traffic_only_for_the_matching_launch_size():
+    """bench.py reports roofline.traffic (HBM-side bytes of the traversal kernel, rocprofv3 --pmc) only from a committed
+    record taken at THIS run's steps / batch depth / resolution / tessellation: the driver's `--steps 20 --warmup 5` line and
+    the default 64-step line each find their own record, anything else gets null with the reason."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("twk_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec, name = bench.pick_pmc_record(20, 20, (1920, 1080))
+    assert rec is not None and name == "r03_trace_hbm_traffic_s20.json" and rec["steps"] == 20 and rec["hbm_bytes_per_launch"] > 1e9
+    rec64, name64 = bench.pick_pmc_record(64, 64, (1920, 1080))
+    assert rec64 is not None and name64 == "r03_trace_hbm_traffic_s64.json" and rec64["hbm_bytes_per_launch"] > 2.5 * rec["hbm_bytes_per_launch"]
+    big, _ = bench.pick_pmc_record(32, 32, (1920, 1080), 2800)
+    assert big is not None and big["sphere_tess"] == 2800 and big["l2_hit_rate"] < 0.5
+    none, why = bench.pick_pmc_record(7, 7, (1920, 1080))
+    assert none is None and "no PMC record at this launch size" in why
+    none, why = bench.pick_pmc_record(20, 20, (3840, 2160))
+    assert none is None
