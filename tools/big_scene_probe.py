@@ -41,7 +41,7 @@ for tess in [int(a) for a in sys.argv[1:]] or [180, 1000, 2800]:
     st = dev.statsGet(True)
     rays = st["radianceRays"] + st["shadowRays"]
     px = app.info.resolution[0] * app.info.resolution[1]
-    print(json.dumps({"instanced_triangles": tris, "upload_and_build_s": round(build_s, 3), "Msamples_per_s": round(px * steps / dt / 1e6, 1),
+    print(json.dumps({"instanced_triangles": tris, "nodes": int(dev.buildInfo()["nodes"]), "upload_and_build_s": round(build_s, 3), "Msamples_per_s": round(px * steps / dt / 1e6, 1),
                       "nodes_per_ray": round(st["nodesVisited"] / rays, 2), "triangles_per_ray": round(st["trianglesTested"] / rays, 2),
                       "max_nodes_per_ray": st["maxNodesPerRay"], "overflow_rays_per_M": round(1e6 * st["overflowRays"] / rays, 2)}), flush=True)
     dev.close()

@@ -6,9 +6,9 @@ namespace twk {
 // Quantised copy of `count` wide nodes (128 B each at wide[2 * i]) into out[4 * i] (64 B each, device_types.h).
 void launchQuantizeWide(const BvhNode* wide, float4* out, int count, hipStream_t stream);
 
-// Copies the first TWK_TOP_NODES quantised wide nodes (breadth-first from `root`) into top[TWK_TOP_NODES * 4] with the
+// Copies the first numSlots (<= TWK_TOP_NODES) quantised wide nodes (breadth-first from `root`) into top[numSlots * 4] with the
 // references among them rewritten to TWK_NODE_CACHED | slot (device_types.h).
-void launchTopCache(const float4* wideQ, int root, float4* top, hipStream_t stream);
+void launchTopCache(const float4* wideQ, int root, float4* top, int numSlots, hipStream_t stream);
 
 // Scratch-owning LBVH builder, reused for every geometry (bottom level) and for the instance level.
 class BvhBuilder

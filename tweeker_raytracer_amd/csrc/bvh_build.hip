@@ -448,7 +448,7 @@ void launchQuantizeWide(const BvhNode* wide, float4* out, int count, hipStream_t
 // Top-of-tree cache (device_types.h TWK_NODE_CACHED): breadth-first from the root over the quantised wide nodes, the
 // first TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One block: thread 0 walks the
 // queue, then one thread per slot copies its node and rewrites its references.
-__global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float4* __restrict__ top)
+__global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float4* __restrict__ top, int numSlots)
 {
   __shared__ int queue[TWK_TOP_NODES];
   __shared__ int count;
@@ -465,14 +465,14 @@ __global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float
       for (int k = 0; k < 4; ++k)
       {
         const bool unused = ((qlx >> (8 * k)) & 0xffu) > ((qhx >> (8 * k)) & 0xffu); // inverted box
-        if (!unused && r[k] >= 0 && r[k] != TWK_BVH_SENTINEL && n < TWK_TOP_NODES) queue[n++] = r[k];
+        if (!unused && r[k] >= 0 && r[k] != TWK_BVH_SENTINEL && n < numSlots) queue[n++] = r[k];
       }
     }
     count = n;
   }
   __syncthreads();
   const int n = count;
-  for (int i = threadIdx.x; i < TWK_TOP_NODES; i += blockDim.x)
+  for (int i = threadIdx.x; i < numSlots; i += blockDim.x)
   {
     float4* out = top + 4 * i;
     if (i >= n) { for (int k = 0; k < 4; ++k) out[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; } // slot never referenced
@@ -487,9 +487,9 @@ __global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float
   }
 }
 
-void launchTopCache(const float4* wideQ, int root, float4* top, hipStream_t stream)
+void launchTopCache(const float4* wideQ, int root, float4* top, int numSlots, hipStream_t stream)
 {
-  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wideQ, root, top);
+  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wideQ, root, top, numSlots < TWK_TOP_NODES ? numSlots : TWK_TOP_NODES);
 }
 
 #define BVH_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)

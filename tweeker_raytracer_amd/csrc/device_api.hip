@@ -104,7 +104,7 @@ struct TwkDevice_t
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
-  float4* d_topNodes = nullptr; bool topCache = true; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
+  float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
   int tlasRoot = 0;
@@ -233,7 +233,7 @@ static void refreshParams(TwkDevice dev)
   p.attributes = dev->d_attributes; p.indices = dev->d_indices;
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
-  p.topNodes = dev->d_topNodes;
+  p.topNodes = dev->d_topNodes; p.topNodes7 = dev->d_topNodes7;
   p.topRoot = dev->topCache ? (TWK_NODE_CACHED | 0) : dev->tlasRoot;
   p.twoLevel = dev->twoLevel ? 1 : 0;
   p.numInstances = (int) dev->instances.size();
@@ -242,6 +242,9 @@ static void refreshParams(TwkDevice dev)
   p.miss = dev->miss;
   p.hasCutout = 0; p.hasAlbedoTexture = 0;
   for (const DevMaterial& m : dev->materials) { if (m.textureCutout != 0) p.hasCutout = 1; if (m.textureAlbedo != 0) p.hasAlbedoTexture = 1; }
+  // seven trace blocks per CU where the variant that fits them applies (device_types.h TWK_TRACE_WAVES7)
+  p.traceWaves = (!dev->twoLevel && !p.hasCutout && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : TWK_TRACE_WAVES;
+  if (dev->traceWavesForced == TWK_TRACE_WAVES || (dev->traceWavesForced == TWK_TRACE_WAVES7 && !dev->twoLevel && !p.hasCutout)) p.traceWaves = dev->traceWavesForced;
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)
   {
@@ -272,7 +275,7 @@ static void refreshParams(TwkDevice dev)
   p.droppedPushes = dev->d_dropped;
 }
 
-static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * TWK_TRACE_WAVES; } // every block resident at once (device_types.h)
+static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * TWK_TRACE_WAVES7; } // the larger of the two persistent grids (sizes the spill stacks); a launch uses numCUs x params.traceWaves
 
 // `samples`: samples per pixel the next wavefront pass carries; the path streams grow to what passes actually need
 // (a 64-sample pass of a 1920x1080 frame takes 46 GB, a handle that renders two iterations takes 1.4 GB).
@@ -547,7 +550,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   const int maxDepth = dev->state.pathLengths[1];
   const int lanes = chooseLanes(dev, p.numPaths);
   // every block of every lane's persistent trace kernel resident at once: the lanes share the CUs' block slots
-  int traceWaves = std::max(1, TWK_TRACE_WAVES / lanes);
+  int traceWaves = std::max(1, p.traceWaves / lanes);
   if (lanes > 1 && dev->laneTraceWaves > 0) traceWaves = std::min(dev->laneTraceWaves, 2 * TWK_TRACE_WAVES / lanes); // TWK_LANE_TRACE_WAVES (experiments; the spill stacks hold two full grids)
   const int traceGrid = dev->numCUs * traceWaves;
 
@@ -670,6 +673,7 @@ try
   if (const char* e = getenv("TWK_PASS_LANES")) dev->lanesForced = std::max(0, std::min(TWK_MAX_LANES, atoi(e)));
   if (const char* e = getenv("TWK_LANE_TRACE_WAVES")) dev->laneTraceWaves = std::max(0, atoi(e));
   if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
   if (const char* e = getenv("TWK_STREAM_BUDGET_MB")) { const long long mb = atoll(e); dev->streamBudgetBytes = (mb > 0) ? (size_t) mb << 20 : 0; }
@@ -691,7 +695,7 @@ try
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
   freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
-  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes);
+  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes); freeDevice(dev->d_topNodes7);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
   freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
   if (dev->h_dropped) { (void) hipHostFree(dev->h_dropped); dev->h_dropped = nullptr; dev->d_dropped = nullptr; }
@@ -1113,7 +1117,9 @@ try
   // the persistent trace kernel reads the quantised copy of the wide nodes; the full-precision ones were scratch
   launchQuantizeWide(dev->d_wideNodes, dev->d_wideQ, (int) numNodes, dev->stream);
   if (!dev->d_topNodes) HIP_TRY(hipMalloc(&dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
-  launchTopCache(dev->d_wideQ, dev->tlasRoot, dev->d_topNodes, dev->stream);
+  if (!dev->d_topNodes7) HIP_TRY(hipMalloc(&dev->d_topNodes7, sizeof(float4) * 4 * TWK_TOP_NODES7));
+  launchTopCache(dev->d_wideQ, dev->tlasRoot, dev->d_topNodes, TWK_TOP_NODES, dev->stream);
+  launchTopCache(dev->d_wideQ, dev->tlasRoot, dev->d_topNodes7, TWK_TOP_NODES7, dev->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
   freeDevice(dev->d_wideNodes);
@@ -1491,7 +1497,7 @@ try
   HIP_TRY(d_ids.allocate(numRays * 2));
   HIP_TRY(hipMemcpyAsync(d_rays.ptr, rays, numRays * 8 * sizeof(float), hipMemcpyHostToDevice, dev->stream));
   int grid = (int) ((numRays + TWK_TRACE_BLOCK - 1) / TWK_TRACE_BLOCK);
-  if (grid > traceGridBlocks(dev)) grid = traceGridBlocks(dev);
+  if (grid > dev->numCUs * TWK_TRACE_WAVES) grid = dev->numCUs * TWK_TRACE_WAVES;
   launchTraceQuery(dev->params, d_rays.ptr, (unsigned int) numRays, anyHit, d_out.ptr, d_ids.ptr, grid, dev->stream);
   HIP_TRY(hipMemcpyAsync(tBetaGamma, d_out.ptr, numRays * 3 * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
   HIP_TRY(hipMemcpyAsync(ids, d_ids.ptr, numRays * 2 * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
@@ -1553,7 +1559,7 @@ try
     const unsigned int c = (unsigned int) numShadow;
     HIP_TRY(hipMemcpy(dev->d_counters + 0 * TWK_COUNTERS_PER_DEPTH + 1, &c, sizeof(c), hipMemcpyHostToDevice));
   }
-  launchTrace(p, 1, false, traceGridBlocks(dev), dev->stream);
+  launchTrace(p, 1, false, dev->numCUs * p.traceWaves, dev->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
   if (numClosest)
@@ -1608,6 +1614,7 @@ try
   q.nodes          = static_cast<const BvhNode*>(host(dev->d_nodes, sizeof(BvhNode) * dev->totalNodes));
   q.wideQ          = static_cast<const float4*>(host(dev->d_wideQ, sizeof(float4) * 4 * dev->totalNodes));
   q.topNodes       = static_cast<const float4*>(host(dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
+  q.topNodes7      = static_cast<const float4*>(host(dev->d_topNodes7, sizeof(float4) * 4 * TWK_TOP_NODES7));
   q.triangles      = static_cast<const float4*>(host(dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles));
   q.shadeTriangles = static_cast<const float4*>(host(dev->d_shadeTriangles, sizeof(float4) * TWK_SHADE_RECORD * dev->totalTriangles));
   q.instances      = static_cast<const DevInstance*>(host(dev->d_instances, sizeof(DevInstance) * dev->instances.size()));

@@ -140,6 +140,7 @@ struct LaunchParams
   // scene
   const BvhNode*     nodes;          // binary nodes (single-ray traversal: query kernel, overflow fallback, tail kernel)
   const float4*      topNodes;       // TWK_TOP_NODES x 4 float4: the cached top of the tree (device_types.h TWK_NODE_CACHED), built by twk_build
+  const float4*      topNodes7;      // the same for the seven-blocks-per-CU variant: TWK_TOP_NODES7 nodes, references among THEM rewritten
   int                topRoot;        // reference the persistent kernel starts at: TWK_NODE_CACHED | 0, or tlasRoot when the cache is off
   const float4*      wideQ;          // quantised 4-ary nodes, 64 bytes = 4 float4 per inner node index (persistent trace kernel; layout above)
   const float4*      triangles;      // 3 per triangle slot: the vertices, .w of the first = primitive id, of the second = instance (world-space slots)
@@ -154,6 +155,7 @@ struct LaunchParams
   const float*       envCDF_U;
   const float*       envCDF_V;
   int   tlasRoot;
+  int   traceWaves;     // blocks per CU of the persistent trace kernel: TWK_TRACE_WAVES, or TWK_TRACE_WAVES7 (flattened scene, no cutout, small: see TWK_TRACE_WAVES7)
   int   twoLevel;       // 0: every instance is flattened — the BVH is one world-space tree (top level + spliced instance trees) and no kernel ever enters an instance
   int   numInstances;
   int   numLights;
@@ -223,6 +225,19 @@ struct LaunchParams
 // resident: 4 / 5 / 6 blocks per CU = 0.94 / 0.88 / 0.84 ms per step.
 #ifndef TWK_TRACE_WAVES
 #define TWK_TRACE_WAVES 6
+#endif
+// The variant of the persistent trace kernel for scenes whose instances are all flattened, without cutout opacity, needs 70
+// VGPRs: SEVEN blocks per CU fit the registers, and the LDS too with a 19-entry stack (the cliff on the shipped scenes is
+// between 18 and 19: 0.673 against 0.536 ms/step at 18) and a 32-node top-of-tree cache (64 -> 32 costs nothing measurable):
+// 7 x (20 KiB + 2.5 KiB) = 157.5 of 160 KiB. Measured, 6 -> 7 blocks per CU: C2 trace 0.536 -> 0.518 ms/step, whole frame
+// +1.7 % (64 iterations) / +2.7 % (20), C4 geometry +2.0 %, a C5 rank's share +3.7 %. The two-level and cutout variants
+// need 76..91 VGPRs and spill at 72 (C4 instances -11 %, C3 -16 %), and scenes of millions of triangles lose 2-6 % (the
+// smaller cache and stack matter there), so those keep six blocks, a 20-entry stack and 64 cached nodes.
+#define TWK_TRACE_WAVES7      7
+#define TWK_TRACE_STACK_LDS7  19
+#define TWK_TOP_NODES7        32
+#ifndef TWK_TRACE_WAVES7_MAX_NODES
+#define TWK_TRACE_WAVES7_MAX_NODES 1000000 // binary nodes (= triangle slots - 1); measured on the Cornell room: +2.7 % at 64 k, +2.3 % at 258 k, +2.9 % at 977 k, -2.5 % at 2.0 M
 #endif
 #define TWK_TRACE_STACK_SPILL 72  // further entries per lane in HBM
 #define TWK_TRACE_BLOCK       256

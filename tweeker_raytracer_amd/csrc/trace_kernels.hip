@@ -86,15 +86,19 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 
 // TWO_LEVEL = false: every instance of the scene is flattened (device_types.h TWK_LEAF_WORLD) — one world-space tree,
 // every leaf a triangle range; the instance entry / exit code is compiled out.
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, TWK_TRACE_WAVES) // blocks per CU = waves per SIMD: device_types.h
+// W7: the seven-blocks-per-CU build of the kernel (device_types.h TWK_TRACE_WAVES7): a 19-entry LDS stack, a 32-node cache.
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7>
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : TWK_TRACE_WAVES) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
-  __shared__ int stackStorage[(TWK_TRACE_STACK_LDS + 1) * TWK_TRACE_BLOCK]; // + 1 dummy row, see the node step
-  __shared__ float4 topCache[TWK_TOP_NODES * TWK_TOP_STRIDE];               // device_types.h TWK_NODE_CACHED
+  constexpr int STACK_LDS = W7 ? TWK_TRACE_STACK_LDS7 : TWK_TRACE_STACK_LDS;
+  constexpr int TOP_NODES = W7 ? TWK_TOP_NODES7 : TWK_TOP_NODES;
+  __shared__ int stackStorage[(STACK_LDS + 1) * TWK_TRACE_BLOCK]; // + 1 dummy row, see the node step
+  __shared__ float4 topCache[TOP_NODES * TWK_TOP_STRIDE];         // device_types.h TWK_NODE_CACHED
   int* ldsStack = stackStorage + threadIdx.x;
   const int stride = TWK_TRACE_BLOCK;
-  for (int i = threadIdx.x; i < TWK_TOP_NODES * 4; i += TWK_TRACE_BLOCK) topCache[(i >> 2) * TWK_TOP_STRIDE + (i & 3)] = p.topNodes[i];
+  const float4* topSource = W7 ? p.topNodes7 : p.topNodes;
+  for (int i = threadIdx.x; i < TOP_NODES * 4; i += TWK_TRACE_BLOCK) topCache[(i >> 2) * TWK_TOP_STRIDE + (i & 3)] = topSource[i];
   __syncthreads();
 
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
@@ -303,12 +307,12 @@ traceKernel(LaunchParams p, int depth)
         bool overflow = false;
         if (hits > 0)
         {
-          // nearest child next, the others pushed far-to-near; row TWK_TRACE_STACK_LDS of the LDS stack is a dummy
+          // nearest child next, the others pushed far-to-near; row STACK_LDS of the LDS stack is a dummy
           // that absorbs the unconditional stores once the stack is full
           node = r0;
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r3; overflow |= (hits > 3) & (sp >= TWK_TRACE_STACK_LDS); sp += (hits > 3);
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r2; overflow |= (hits > 2) & (sp >= TWK_TRACE_STACK_LDS); sp += (hits > 2);
-          ldsStack[min(sp, TWK_TRACE_STACK_LDS) * stride] = r1; overflow |= (hits > 1) & (sp >= TWK_TRACE_STACK_LDS); sp += (hits > 1);
+          ldsStack[min(sp, STACK_LDS) * stride] = r3; overflow |= (hits > 3) & (sp >= STACK_LDS); sp += (hits > 3);
+          ldsStack[min(sp, STACK_LDS) * stride] = r2; overflow |= (hits > 2) & (sp >= STACK_LDS); sp += (hits > 2);
+          ldsStack[min(sp, STACK_LDS) * stride] = r1; overflow |= (hits > 1) & (sp >= STACK_LDS); sp += (hits > 1);
         }
         else
         {
@@ -354,7 +358,7 @@ traceKernel(LaunchParams p, int depth)
             const float4* rec = reinterpret_cast<const float4*>(p.instances + payload);
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             if (COUNT) ++instCount;
-            if (sp + 5 > TWK_TRACE_STACK_LDS) state = (state & ~ST_HAS_RAY) | ST_DONE | ST_RETRACE;
+            if (sp + 5 > STACK_LDS) state = (state & ~ST_HAS_RAY) | ST_DONE | ST_RETRACE;
             else
             {
               // below the sentinel: the world-space Woop constants, restored when the sentinel is popped
@@ -608,27 +612,34 @@ traceQueryKernel(LaunchParams p, const float* __restrict__ rays, unsigned int nu
   }
 }
 
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL>
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7>
 static void launchTraceVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
-  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
   hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
 }
 
+// gridBlocks must be numCUs x p.traceWaves (or a lane's share of it): every block of the persistent kernel resident at once.
 void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream)
 {
+  if (p.traceWaves == TWK_TRACE_WAVES7 && !p.hasCutout && !p.twoLevel)
+  {
+    if (count) launchTraceVariant<true,  false, false, true>(p, depth, gridBlocks, stream);
+    else       launchTraceVariant<false, false, false, true>(p, depth, gridBlocks, stream);
+    return;
+  }
   const int variant = (count ? 4 : 0) | (p.hasCutout ? 2 : 0) | (p.twoLevel ? 1 : 0);
   switch (variant)
   {
-    case 0: launchTraceVariant<false, false, false>(p, depth, gridBlocks, stream); break;
-    case 1: launchTraceVariant<false, false, true >(p, depth, gridBlocks, stream); break;
-    case 2: launchTraceVariant<false, true,  false>(p, depth, gridBlocks, stream); break;
-    case 3: launchTraceVariant<false, true,  true >(p, depth, gridBlocks, stream); break;
-    case 4: launchTraceVariant<true,  false, false>(p, depth, gridBlocks, stream); break;
-    case 5: launchTraceVariant<true,  false, true >(p, depth, gridBlocks, stream); break;
-    case 6: launchTraceVariant<true,  true,  false>(p, depth, gridBlocks, stream); break;
-    default: launchTraceVariant<true, true,  true >(p, depth, gridBlocks, stream); break;
+    case 0: launchTraceVariant<false, false, false, false>(p, depth, gridBlocks, stream); break;
+    case 1: launchTraceVariant<false, false, true,  false>(p, depth, gridBlocks, stream); break;
+    case 2: launchTraceVariant<false, true,  false, false>(p, depth, gridBlocks, stream); break;
+    case 3: launchTraceVariant<false, true,  true,  false>(p, depth, gridBlocks, stream); break;
+    case 4: launchTraceVariant<true,  false, false, false>(p, depth, gridBlocks, stream); break;
+    case 5: launchTraceVariant<true,  false, true,  false>(p, depth, gridBlocks, stream); break;
+    case 6: launchTraceVariant<true,  true,  false, false>(p, depth, gridBlocks, stream); break;
+    default: launchTraceVariant<true, true,  true,  false>(p, depth, gridBlocks, stream); break;
   }
 }
 
