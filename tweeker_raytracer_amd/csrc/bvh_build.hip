@@ -209,6 +209,13 @@ TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const 
 // get an empty box. Wide nodes share the index space of the binary nodes (every inner node has one; only those at
 // even depth below the root are ever visited).
 struct WideEntry { float4 lo, hi; int ref; };
+#ifndef TWK_WIDE_GREEDY
+// 1: instead of the four grandchildren, open twice the inner entry with the largest surface area (the usual collapse of a
+// binary tree into wide nodes). Measured in round 3 on the binned-SAH trees (profiles/r03y_wide_collapse_greedy.txt): node
+// visits per ray 7.64 -> 7.43 on C2, but triangle tests 3.07 -> 3.28 and the LDS stack overflows where it never did;
+// C2 2 600 -> 2 410 Msamples/s, C4 geometry -5 %, 2.0 M triangles -14 %, 15.7 M -17 %. Not used.
+#define TWK_WIDE_GREEDY 0
+#endif
 
 TWK_D void emptyEntry(WideEntry& e)
 {
@@ -306,8 +313,33 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
     {
       WideEntry e[4];
       int n = 0;
+#if TWK_WIDE_GREEDY
+      // the two children, then twice: the inner entry with the largest surface area gives way to its own two children
+      // (the binary nodes below are final: this walk is bottom-up)
+      e[0].lo = lo0; e[0].hi = hi0; e[0].ref = c0;
+      e[1].lo = lo1; e[1].hi = hi1; e[1].ref = c1;
+      n = 2;
+      for (int step = 0; step < 2; ++step)
+      {
+        int best = -1;
+        float bestArea = -1.0f;
+        for (int k = 0; k < n; ++k)
+        {
+          if (e[k].ref < 0) continue;
+          const float dx = e[k].hi.x - e[k].lo.x, dy = e[k].hi.y - e[k].lo.y, dz = e[k].hi.z - e[k].lo.z;
+          const float area = dx * dy + dy * dz + dz * dx;
+          if (area > bestArea) { bestArea = area; best = k; }
+        }
+        if (best < 0) break;
+        WideEntry two[2];
+        int m = 0;
+        expandChild(outNodes, nodeBase, e[best].ref, e[best].lo, e[best].hi, two, m);
+        e[best] = two[0]; e[n++] = two[1];
+      }
+#else
       expandChild(outNodes, nodeBase, c0, lo0, hi0, e, n);
       expandChild(outNodes, nodeBase, c1, lo1, hi1, e, n);
+#endif
       for (; n < 4; ++n) emptyEntry(e[n]);
       writeWideNode(&outWide[2 * node], e);
     }
