@@ -296,6 +296,11 @@ traceKernel(LaunchParams p, int depth)
         const bool h3 = TWK_SLAB(3, t3);
 #undef TWK_SLAB
 #undef TWK_Q
+        // (Round 3: any-hit rays — the shadow rays of a scene without cutout opacity, a third of all rays, most of which hit
+        // nothing and visit every node on their segment in any order — taking the children that were hit in memory order: three
+        // selects instead of the 29 vector instructions of the sort below. Chosen per wave (the queue is dealt closest-hit
+        // rays first, waves are nearly always of one kind) by a uniform branch in this step: visits +0.4 %, C2 2 585 -> 2 530
+        // Msamples/s; as one node loop per kind of wave: 8 registers spilled, 2 355. tools/experiments/, profiles/r03y_any_hit_unordered.txt.)
         const float inf = __uint_as_float(0x7f800000u);
         t0 = h0 ? t0 : inf; t1 = h1 ? t1 : inf; t2 = h2 ? t2 : inf; t3 = h3 ? t3 : inf;
         // sort the four (entry distance, reference) pairs, misses last: 5 compare-exchanges
