@@ -44,6 +44,10 @@ public:
   // single-ray traversal may have to keep on its stack.
   int    lastHeight() const { return m_lastHeight; }
   void setMaxLeaf(int n) { m_maxLeaf = (n < 1) ? 1 : ((n > 4) ? 4 : n); } // count - 1 takes two bits of a leaf reference
+  int    maxLeaf() const { return m_maxLeaf; }
+  // Expected wide-node visits per node (bvh_build.hip refitKernel), one float per node of the scene's node array, absolute
+  // index: with it every wide node takes the cheaper of its possible cuts; nullptr: the four grandchildren.
+  void   setNodeCost(float* absolute) { m_nodeCost = absolute; }
 
 private:
   hipError_t reserve(int count);
@@ -74,6 +78,7 @@ private:
   int* m_sahCounters = nullptr; double* m_sahCost = nullptr;
   double m_lastSahInner = 0.0, m_lastSahLeaf = 0.0;
   int    m_lastHeight = 0;
+  float* m_nodeCost = nullptr;
   void* m_sortTemp = nullptr; size_t m_sortBytes = 0;
 };
 

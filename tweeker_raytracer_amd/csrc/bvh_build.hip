@@ -209,13 +209,13 @@ TWK_D void writeNode(BvhNode* node, const float4& lo0, const float4& hi0, const 
 // get an empty box. Wide nodes share the index space of the binary nodes (every inner node has one; only those at
 // even depth below the root are ever visited).
 struct WideEntry { float4 lo, hi; int ref; };
-#ifndef TWK_WIDE_GREEDY
-// 1: instead of the four grandchildren, open twice the inner entry with the largest surface area (the usual collapse of a
-// binary tree into wide nodes). Measured in round 3 on the binned-SAH trees (profiles/r03y_wide_collapse_greedy.txt): node
-// visits per ray 7.64 -> 7.43 on C2, but triangle tests 3.07 -> 3.28 and the LDS stack overflows where it never did;
-// C2 2 600 -> 2 410 Msamples/s, C4 geometry -5 %, 2.0 M triangles -14 %, 15.7 M -17 %. Not used.
-#define TWK_WIDE_GREEDY 0
-#endif
+// (Round 3, measured and not kept: opening twice the inner entry with the largest surface area instead of taking the four
+// grandchildren — node visits per ray 7.64 -> 7.43 on C2, triangle tests 3.07 -> 3.28, C2 -7 %: profiles/r03y_wide_collapse_greedy.txt.)
+TWK_D float wideHalfArea(const float4& lo, const float4& hi)
+{
+  const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  return dx * dy + dy * dz + dz * dx;
+}
 
 TWK_D void emptyEntry(WideEntry& e)
 {
@@ -266,7 +266,7 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
                             const int2* __restrict__ range,
                             unsigned int* __restrict__ tickets, float4* nodeLo, float4* nodeHi,
                             BvhNode* outNodes, BvhNode* __restrict__ outWide, int nodeBase, int leafMode, int leafBase, int maxLeaf,
-                            const int* __restrict__ leafPayload, int leafFlag)
+                            const int* __restrict__ leafPayload, int leafFlag, float* nodeCost /* indexed by absolute node index; nullptr: every wide node = the four grandchildren */)
 {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= count) return;
@@ -313,33 +313,49 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
     {
       WideEntry e[4];
       int n = 0;
-#if TWK_WIDE_GREEDY
-      // the two children, then twice: the inner entry with the largest surface area gives way to its own two children
-      // (the binary nodes below are final: this walk is bottom-up)
-      e[0].lo = lo0; e[0].hi = hi0; e[0].ref = c0;
-      e[1].lo = lo1; e[1].hi = hi1; e[1].ref = c1;
-      n = 2;
-      for (int step = 0; step < 2; ++step)
+      if (nodeCost != nullptr)
       {
-        int best = -1;
-        float bestArea = -1.0f;
-        for (int k = 0; k < n; ++k)
+        // Which of the two children give way to their own children in this node's wide node: the cut with the fewest
+        // expected wide-node visits below this node, N(i) = 1 + sum over the inner entries e of area(e) / area(i) * N(e)
+        // (leaf entries are reached with the same probability under every cut). The binary nodes and the N of everything
+        // below are final: this walk is bottom-up.
+        WideEntry child[2], grand[2][2];
+        child[0].lo = lo0; child[0].hi = hi0; child[0].ref = c0;
+        child[1].lo = lo1; child[1].hi = hi1; child[1].ref = c1;
+        const float areaNode = wideHalfArea(make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f),
+                                            make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f));
+        const float scale = (areaNode > 0.0f) ? 1.0f / areaNode : 0.0f;
+        float keep[2], open[2]; // expected visits below child k when it stays one entry / when its children take its place
+        for (int k = 0; k < 2; ++k)
         {
-          if (e[k].ref < 0) continue;
-          const float dx = e[k].hi.x - e[k].lo.x, dy = e[k].hi.y - e[k].lo.y, dz = e[k].hi.z - e[k].lo.z;
-          const float area = dx * dy + dy * dz + dz * dx;
-          if (area > bestArea) { bestArea = area; best = k; }
+          keep[k] = 0.0f; open[k] = 0.0f;
+          if (child[k].ref < 0) continue;
+          keep[k] = fminf(wideHalfArea(child[k].lo, child[k].hi) * scale, 1.0f) * nodeCost[child[k].ref];
+          int m = 0;
+          expandChild(outNodes, nodeBase, child[k].ref, child[k].lo, child[k].hi, grand[k], m);
+          for (int g = 0; g < 2; ++g)
+            if (grand[k][g].ref >= 0) open[k] += fminf(wideHalfArea(grand[k][g].lo, grand[k][g].hi) * scale, 1.0f) * nodeCost[grand[k][g].ref];
         }
-        if (best < 0) break;
-        WideEntry two[2];
-        int m = 0;
-        expandChild(outNodes, nodeBase, e[best].ref, e[best].lo, e[best].hi, two, m);
-        e[best] = two[0]; e[n++] = two[1];
+        float best = 0.0f;
+        int bestMask = -1;
+        for (int mask = 3; mask >= 0; --mask) // ties: the wider node
+        {
+          if (((mask & 1) && c0 < 0) || ((mask & 2) && c1 < 0)) continue;
+          const float cost = 1.0f + ((mask & 1) ? open[0] : keep[0]) + ((mask & 2) ? open[1] : keep[1]);
+          if (bestMask < 0 || cost < best) { best = cost; bestMask = mask; }
+        }
+        for (int k = 0; k < 2; ++k)
+        {
+          if (bestMask & (1 << k)) { e[n++] = grand[k][0]; e[n++] = grand[k][1]; }
+          else e[n++] = child[k];
+        }
+        nodeCost[nodeBase + node] = best;
       }
-#else
-      expandChild(outNodes, nodeBase, c0, lo0, hi0, e, n);
-      expandChild(outNodes, nodeBase, c1, lo1, hi1, e, n);
-#endif
+      else
+      {
+        expandChild(outNodes, nodeBase, c0, lo0, hi0, e, n);
+        expandChild(outNodes, nodeBase, c1, lo1, hi1, e, n);
+      }
       for (; n < 4; ++n) emptyEntry(e[n]);
       writeWideNode(&outWide[2 * node], e);
     }
@@ -352,8 +368,9 @@ __global__ void refitKernel(const unsigned long long* __restrict__ keys, int cou
 // A single primitive has no inner node: emit one node whose second child can never be hit.
 __global__ void singleLeafKernel(const float4* __restrict__ primLo, const float4* __restrict__ primHi,
                                  BvhNode* outNodes, BvhNode* outWide, float4* nodeLo, float4* nodeHi, int leafMode, int leafBase,
-                                 const int* __restrict__ leafPayload, int leafFlag)
+                                 const int* __restrict__ leafPayload, int leafFlag, float* nodeCost)
 {
+  if (nodeCost != nullptr) nodeCost[0] = 1.0f;
   const int leafRef = (leafMode == 0) ? ~(leafBase | leafFlag) : ~leafPayload[0];
   float4 lo = primLo[0], hi = primHi[0];
   padBox(lo, hi);
@@ -570,7 +587,7 @@ hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* ou
   const int grid  = (count + block - 1) / block;
   if (count == 1)
   {
-    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, outWide, m_nodeLo, m_nodeHi, leafMode, leafBase, m_leafPayload, leafFlag);
+    hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(1), 0, stream, m_primLo, m_primHi, outNodes, outWide, m_nodeLo, m_nodeHi, leafMode, leafBase, m_leafPayload, leafFlag, m_nodeCost ? m_nodeCost + nodeBase : nullptr);
     // keysOut[0] must still name primitive 0 for emitTriangles
     BVH_CHECK(hipMemsetAsync(m_keysOut, 0, sizeof(unsigned long long), stream));
     return hipGetLastError();
@@ -587,7 +604,7 @@ hipError_t BvhBuilder::buildFromBoxes(hipStream_t stream, int count, BvhNode* ou
   }
   BVH_CHECK(hipMemsetAsync(m_tickets, 0, sizeof(unsigned int) * count, stream));
   hipLaunchKernelGGL(refitKernel, dim3(grid), dim3(block), 0, stream, m_keysOut, count, m_primLo, m_primHi, m_left, m_right,
-                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, outWide, nodeBase, leafMode, leafBase, m_maxLeaf, m_leafPayload, leafFlag);
+                     m_innerParent, m_leafParent, m_range, m_tickets, m_nodeLo, m_nodeHi, outNodes, outWide, nodeBase, leafMode, leafBase, m_maxLeaf, m_leafPayload, leafFlag, m_nodeCost);
   BVH_CHECK(hipGetLastError());
   return (leafMode == 0) ? accumulateSahCost(stream, count) : hipSuccess;
 }

@@ -104,7 +104,7 @@ struct TwkDevice_t
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
-  float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
+  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
   int tlasRoot = 0;
@@ -673,6 +673,8 @@ try
   if (const char* e = getenv("TWK_PASS_LANES")) dev->lanesForced = std::max(0, std::min(TWK_MAX_LANES, atoi(e)));
   if (const char* e = getenv("TWK_LANE_TRACE_WAVES")) dev->laneTraceWaves = std::max(0, atoi(e));
   if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_DIRECT_SMALL_LEAVES")) dev->directSmallLeaves = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_COSTED_CUTS")) dev->costedCuts = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
@@ -1023,6 +1025,10 @@ try
   }
 
   if (const char* e = getenv("TWK_MAX_LEAF")) dev->builder.setMaxLeaf(atoi(e)); // tuning knob, default 2 triangles per leaf
+  ScopedDeviceBuffer<float> nodeCost; // expected wide-node visits below each node: what the wide nodes' cuts are chosen by (bvh_build.hip refitKernel)
+  if (dev->costedCuts) HIP_TRY(nodeCost.allocate(numNodes));
+  struct NodeCostScope { BvhBuilder& b; ~NodeCostScope() { b.setNodeCost(nullptr); } } nodeCostScope{dev->builder}; // the array does not outlive this call
+  dev->builder.setNodeCost(nodeCost.ptr);
   int maxEnteredHeight = 0, maxFlatHeight = 0, topHeight = 0; // binary-tree heights: what a traversal stack may have to hold
   // bottom level: one LBVH per entered geometry, shared by all of its instances (Device.cpp:1339 caches the GAS per Triangles id)
   for (size_t k = 0; k < dev->geometries.size(); ++k)
@@ -1073,6 +1079,11 @@ try
       boxLo[i] = make_float4(bounds[0], bounds[1], bounds[2], 0.0f);
       boxHi[i] = make_float4(bounds[3], bounds[4], bounds[5], 0.0f);
       leafPayload[i] = ~flatNodeBase[i]; // child reference ~payload = the instance's root node: an inner reference
+      // A flattened instance of no more triangles than a leaf holds (a wall, the area light: two triangles) IS a leaf of the
+      // top level: its slots are referenced directly instead of through a one-node tree of two single-triangle leaves —
+      // one node visit and one leaf step less for every ray that crosses its box (C2: six of the eight instances).
+      if (dev->directSmallLeaves && g.numTriangles <= dev->builder.maxLeaf() && g.numTriangles <= 4)
+        leafPayload[i] = flatTriangleBase[i] | ((g.numTriangles - 1) << 28) | TWK_LEAF_WORLD;
       continue;
     }
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
