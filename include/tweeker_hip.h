@@ -27,7 +27,7 @@ extern "C" {
 
 /* 3: TwkLaunchStats grew by waveCycles[6] (twk_stats_get writes sizeof(TwkLaunchStats) bytes) and
  * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
-#define TWK_ABI_VERSION 4
+#define TWK_ABI_VERSION 5
 
 typedef enum TwkResult
 {
@@ -228,6 +228,8 @@ typedef struct TwkBuildInfo
   double   buildMilliseconds; /* host wall time of twk_build, uploads included */
   uint64_t triangleSlots, nodes, instances, flattenedInstances;
   uint64_t maxTraversalDepth; /* ABI 4: binary-tree levels of the deepest root-to-leaf path (top level + the deepest tree below it); twk_build refuses a scene deeper than the traversal stacks */
+  uint64_t directLeafInstances; /* ABI 5: flattened instances of at most a leaf's triangles that ARE leaves of the top level (no tree of their own is visited) */
+  uint64_t traceBlocksPerCU;    /* ABI 5: resident blocks per CU of the persistent traversal kernel for this scene with the materials as they are now: 6, or 7 (flattened, no cutout opacity, at most 1 M nodes) */
 } TwkBuildInfo;
 int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info);
 

@@ -12,5 +12,5 @@ for v in "$@"; do
   rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/sq2 -o sq2 -- python3 bench.py $ARGS > $OUT/sq2.log 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_FLAT --kernel-trace --output-format csv -d $OUT/sq3 -o sq3 -- python3 bench.py $ARGS > $OUT/sq3.log 2>&1
   python3 tools/pmc_summarize.py $OUT gpurun_out/$TAG/$v.md > /dev/null
-  grep -A 30 "traceKernel<false, false, false>" gpurun_out/$TAG/$v.md | head -34
+  grep -A 30 "traceKernel<false, false, false" gpurun_out/$TAG/$v.md | head -34
 done

@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    for k in ("traceKernel<false, false, false>", "traceKernel<false, false, true>", "traceKernel<false, true", "traceKernel<true", "shadeKernel", "generateKernel", "accumulateKernel"):
+    for k in ("traceKernel<false, false, false, true>", "traceKernel<false, false, false, false>", "traceKernel<false, false, true", "traceKernel<false, true", "traceKernel<true", "shadeKernel", "generateKernel", "accumulateKernel"):
         if k in name:
             return k
     return None

@@ -80,7 +80,8 @@ class AccelerationInfo(C.Structure):
 class BuildInfo(C.Structure):
     _fields_ = [("quality", C.c_int), ("trees", C.c_int), ("sahInnerCost", C.c_double), ("sahLeafCost", C.c_double),
                 ("buildMilliseconds", C.c_double), ("triangleSlots", C.c_uint64), ("nodes", C.c_uint64),
-                ("instances", C.c_uint64), ("flattenedInstances", C.c_uint64), ("maxTraversalDepth", C.c_uint64)]
+                ("instances", C.c_uint64), ("flattenedInstances", C.c_uint64), ("maxTraversalDepth", C.c_uint64),
+                ("directLeafInstances", C.c_uint64), ("traceBlocksPerCU", C.c_uint64)]
 
 
 class AppInfo(C.Structure):

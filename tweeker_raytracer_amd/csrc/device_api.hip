@@ -943,6 +943,8 @@ try
 {
   if (!dev || !info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_get_build_info: NULL argument");
   if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_get_build_info: twk_build has not been called");
+  refreshParams(dev); // the traversal kernel variant depends on the materials as they are now
+  dev->buildInfo.traceBlocksPerCU = (uint64_t) dev->params.traceWaves;
   *info = dev->buildInfo;
   return TWK_SUCCESS;
 }
@@ -1083,7 +1085,10 @@ try
       // top level: its slots are referenced directly instead of through a one-node tree of two single-triangle leaves —
       // one node visit and one leaf step less for every ray that crosses its box (C2: six of the eight instances).
       if (dev->directSmallLeaves && g.numTriangles <= dev->builder.maxLeaf() && g.numTriangles <= 4)
+      {
         leafPayload[i] = flatTriangleBase[i] | ((g.numTriangles - 1) << 28) | TWK_LEAF_WORLD;
+        info.directLeafInstances += 1;
+      }
       continue;
     }
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
