@@ -24,11 +24,11 @@ int twkSetError(int code, const std::string& message)
 }
 
 namespace twk {
-void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream);
+void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream);
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream);
 void launchGenerate(const LaunchParams& p, hipStream_t stream);
 void launchTail(const LaunchParams& p, int depth0, bool count, int gridBlocks, hipStream_t stream);
-void launchShade(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream);
+void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream);
 void launchAccumulate(const LaunchParams& p, hipStream_t stream);
 void launchCompositor(const float4* tiles, float4* output, int width, int height, int launchWidth, int deviceCount,
                       int tileSizeX, int tileShiftX, int tileShiftY, hipStream_t stream);
@@ -104,7 +104,7 @@ struct TwkDevice_t
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
-  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
+  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
   int tlasRoot = 0;
@@ -589,16 +589,27 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
     if (grid > dev->numCUs * TWK_SHADE_BLOCKS_PER_CU) grid = dev->numCUs * TWK_SHADE_BLOCKS_PER_CU;
     laneP[active] = q; laneS[active] = stream; shadeGrid[active] = grid; ++active;
   }
-  for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_GENERATE, laneS[k]); launchGenerate(laneP[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+  // Primary rays are computed by the first traversal and the first shade launch instead of being written by generateKernel and
+  // read back (shade_kernels.hip "primary rays") — unless the scene has cutout opacity (its draws come from the seed IN the
+  // queue) or the paths have no bounce to be shaded in.
+  const bool fusedPrimary = dev->fusedPrimary && wavefrontDepth >= 1 && !p.hasCutout;
+  for (int k = 0; k < active; ++k)
+  {
+    if (fusedPrimary) { const unsigned int numPaths = (unsigned int) laneP[k].numPaths; HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) laneP[k].counters, (int) numPaths, 1, laneS[k])); continue; } // length of queue 0
+    timedLaunchBegin(dev, TWK_KERNEL_GENERATE, laneS[k]); launchGenerate(laneP[k], laneS[k]); timedLaunchEnd(dev, laneS[k]);
+  }
   for (int depth = 0; depth < wavefrontDepth; ++depth)
   {
-    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], depth, dev->statsEnabled, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
-    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_SHADE, laneS[k]); launchShade(laneP[k], depth, shadeGrid[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+    const bool primary = fusedPrimary && depth == 0;
+    // (the PRIMARY build of the traversal kernel needs more registers than seven blocks per CU leave: six at most)
+    const int grid = (primary && TWK_PRIMARY_SIX) ? std::min(traceGrid, dev->numCUs * std::max(1, TWK_TRACE_WAVES / lanes)) : traceGrid;
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], depth, dev->statsEnabled, primary, grid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_SHADE, laneS[k]); launchShade(laneP[k], depth, primary, shadeGrid[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
   if (maxDepth > 0)
   {
     // closest hits of queue `wavefrontDepth` (empty when wavefrontDepth == maxDepth) + the shadow rays of the last shade
-    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], wavefrontDepth, dev->statsEnabled, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], wavefrontDepth, dev->statsEnabled, false, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
   if (wavefrontDepth < maxDepth)
   {
@@ -675,6 +686,7 @@ try
   if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
   if (const char* e = getenv("TWK_DIRECT_SMALL_LEAVES")) dev->directSmallLeaves = (atoi(e) != 0);
   if (const char* e = getenv("TWK_COSTED_CUTS")) dev->costedCuts = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_FUSED_PRIMARY")) dev->fusedPrimary = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
@@ -1575,7 +1587,7 @@ try
     const unsigned int c = (unsigned int) numShadow;
     HIP_TRY(hipMemcpy(dev->d_counters + 0 * TWK_COUNTERS_PER_DEPTH + 1, &c, sizeof(c), hipMemcpyHostToDevice));
   }
-  launchTrace(p, 1, false, dev->numCUs * p.traceWaves, dev->stream);
+  launchTrace(p, 1, false, false, dev->numCUs * p.traceWaves, dev->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
   if (numClosest)

@@ -462,10 +462,17 @@ struct ShadeOutput
 // ENV / TEX: kernel variants (shade_kernels.hip launchShade). A scene without the spherical environment map (miss != 2) and
 // without an albedo texture on any material runs a variant with both compiled out: 107 instead of 113 VGPRs, no scratch
 // (the full kernel spills 9 dwords), 30 instead of 36 KB of code; measured on C2: shade 0.290 -> 0.273 ms per step.
-template<bool ENV = true, bool TEX = true>
+// PRIMARY: the first segment of a path whose generateKernel was skipped (shade_kernels.hip "primary rays"): this call owns the
+// path's radiance and AOV words and initialises them (raygeneration.cu:53-62) instead of adding to them.
+template<bool ENV = true, bool TEX = true, bool PRIMARY = false>
 TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const float4& ro, const float4& rd,
                      const float4& hit, int instanceIndex, ShadeOutput& out)
 {
+  if (PRIMARY && p.pathAlbedo != nullptr)
+  {
+    p.pathAlbedo[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // Optix7Gui raygeneration.cu:66-71: black, null vector
+    p.pathNormal[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   const float4 tp = out.throughputPdf;
   const uint2  sf = out.seedFlags;
   V3 throughput = v3(tp.x, tp.y, tp.z);
@@ -703,7 +710,13 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   out.shadowDir = shadowDir; out.shadowTmax = shadowTmax;
   out.pending = throughput * contribution;
   out.shadowSeed = (wantShadow && p.hasCutout) ? tea<2>(prd.seed, 0x53484457u /* 'SHDW' */) : 0u;
-  if (!wantShadow)
+  if (PRIMARY)
+  {
+    // black radiance (raygeneration.cu:55) + what this segment adds: 0.0f + x is x, bit for bit, unless x is -0.0f
+    const V3 add = wantShadow ? v3(0.0f) : throughput * prd.radiance;
+    p.pathRadiance[pixel] = make_float4(0.0f + add.x, 0.0f + add.y, 0.0f + add.z, 1.0f);
+  }
+  else if (!wantShadow)
   {
     // emission / environment (or nothing): radiance += throughput * prd.radiance
     float4 r = p.pathRadiance[pixel];
@@ -751,9 +764,12 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Body of generateKernel for path `index` of the launch (shade_kernels.hip; also what the host build of the kernels runs:
-// oracle/host_kernels.cpp).
-TWK_D void generatePath(const LaunchParams& p, const unsigned int index)
+// The primary ray of path `index` of the launch (raygeneration.cu:167-203 up to the first optixTrace, lens_shader.cu): seed,
+// jitter, lens shader. generateKernel stores it; on the fused path (shade_kernels.hip "primary rays") the first traversal and
+// the first shade launch each compute it instead of passing it through memory — the same function, the same bits.
+struct PrimaryRay { V3 origin, direction; unsigned int seed; bool active; };
+
+TWK_D PrimaryRay primaryRay(const LaunchParams& p, const unsigned int index)
 {
   const unsigned int path = index + (unsigned int) p.pathBase; // path of the whole pass; `index` counts within this launch's lane
   const unsigned int sampleIndex = path / (unsigned int) p.numPixels;
@@ -813,6 +829,20 @@ TWK_D void generatePath(const LaunchParams& p, const unsigned int index)
       direction = normalize(U * ndcX + V * ndcY + W);
     }
   }
+
+  PrimaryRay r;
+  r.origin = origin; r.direction = direction; r.seed = seed; r.active = active;
+  return r;
+}
+
+// Body of generateKernel for path `index` of the launch (shade_kernels.hip; also what the host build of the kernels runs:
+// oracle/host_kernels.cpp).
+TWK_D void generatePath(const LaunchParams& p, const unsigned int index)
+{
+  const PrimaryRay ray = primaryRay(p, index);
+  const V3 origin = ray.origin, direction = ray.direction;
+  const unsigned int seed = ray.seed;
+  const bool active = ray.active;
 
   // integrator prologue (raygeneration.cu:53-62): black radiance, unit throughput, empty volume stack
   p.pathRadiance[index]   = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);

@@ -60,9 +60,26 @@ struct ShadeInput
   bool inRange;
 };
 
+// PRIMARY ("primary rays" below): queue 0 was never written; the slot's ray and path state are computed.
+template<bool PRIMARY>
 TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsigned int numRays, ShadeInput& in)
 {
   in.inRange = slot < numRays;
+  if (PRIMARY)
+  {
+    if (in.inRange)
+    {
+      const PrimaryRay ray = primaryRay(p, slot);
+      in.ro = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, p.sceneEpsilon);
+      in.rd = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.active ? RT_DEFAULT_MAX : -1.0f);
+      in.pixel = slot;
+      in.hit = p.hitRecord[slot];
+      in.instanceIndex = p.hitInstance[slot];
+      in.throughputPdf = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      in.seedFlags = make_uint2(ray.seed, 0u);
+    }
+    return;
+  }
   if (in.inRange)
   {
     in.ro = p.rayOrg[q][slot];
@@ -79,8 +96,17 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
 // (s_waitcnt vmcnt(0)), which is exactly what the two barriers of the append must not do: see shadeKernel.
 TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template<bool ENV, bool TEX>
-__global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : TWK_SHADE_WAVES) shadeKernel(LaunchParams p, int depth)
+// Primary rays. A pass used to start with generateKernel writing queue 0 — ray, pixel, throughput, seed and the black radiance
+// of every path, 76 bytes each, 157 MB per C2 iteration at the HBM write rate — for the first traversal and the first shade
+// launch to read back. Both now COMPUTE the primary ray of their slot (shade_device.h primaryRay: 60 integer operations for
+// the seed, two draws, the lens shader) — PRIMARY variants of traceKernel and shadeKernel, launched at depth 0 — and the first
+// shade launch writes the path's radiance instead of adding to it. device_api.hip renderPass keeps generateKernel for what
+// the fused path does not cover (cutout opacity draws from the seed IN the queue; no bounce at all).
+#ifndef TWK_SHADE_WAVES_PRIMARY
+#define TWK_SHADE_WAVES_PRIMARY 4 // the PRIMARY variant carries the ray generation: 13 registers spilled at five waves
+#endif
+template<bool ENV, bool TEX, bool PRIMARY>
+__global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
   // of iteration i + 1, so no third barrier per iteration is needed.
@@ -100,7 +126,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : T
   // short: the streams of the NEXT iteration's slot are requested between the two barriers of the append — they fly
   // while the block waits for its returning atomic — and nothing waits for the appended records to be written.
   ShadeInput in;
-  loadShadeInput(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, in);
+  loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, in);
   unsigned int buffer = 0u;
 
   // block-uniform trip count: every thread reaches both barriers of every iteration
@@ -113,9 +139,10 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : T
     {
       out.throughputPdf = in.throughputPdf;
       out.seedFlags     = in.seedFlags;
-      shadePath<ENV, TEX>(p, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
+      shadePath<ENV, TEX, PRIMARY>(p, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
       if (p.stats != nullptr) { if (in.instanceIndex < 0) ++statMiss; else ++statHit; }
     }
+    else if (PRIMARY && in.inRange) p.pathRadiance[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // inactive launch index: weight 0, as generateKernel leaves it
 
     const unsigned long long shadowMask = __ballot(out.wantShadow);
     const unsigned long long nextMask   = __ballot(out.alive);
@@ -127,7 +154,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : T
     ldsBarrier();
     // (hipcc still waits for part of these right here — it copies one component of the hit record to another register
     // behind the loads; pinning the record at its first use makes that worse, every component then gets such a copy)
-    loadShadeInput(p, q, base + gridDim.x * blockDim.x + threadIdx.x, numRays, in);
+    loadShadeInput<PRIMARY>(p, q, base + gridDim.x * blockDim.x + threadIdx.x, numRays, in);
     if (threadIdx.x < 2)
     {
       unsigned int total = 0;
@@ -316,14 +343,21 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);
 }
-void launchShade(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
+template<bool PRIMARY>
+static void launchShadeVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
   const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
-  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else             hipLaunchKernelGGL((shadeKernel<false, false>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+}
+// primary: depth 0 of a pass whose generateKernel was skipped ("primary rays" above)
+void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream)
+{
+  if (primary) launchShadeVariant<true>(p, depth, gridBlocks, stream);
+  else         launchShadeVariant<false>(p, depth, gridBlocks, stream);
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {

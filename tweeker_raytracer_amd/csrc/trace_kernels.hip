@@ -87,7 +87,9 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // TWO_LEVEL = false: every instance of the scene is flattened (device_types.h TWK_LEAF_WORLD) — one world-space tree,
 // every leaf a triangle range; the instance entry / exit code is compiled out.
 // W7: the seven-blocks-per-CU build of the kernel (device_types.h TWK_TRACE_WAVES7): a 19-entry LDS stack, a 32-node cache.
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7>
+// PRIMARY: depth 0 of a pass without generateKernel — the lane computes the primary ray of its slot instead of fetching it
+// (shade_kernels.hip "primary rays"); never together with CUTOUT.
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
 __global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : TWK_TRACE_WAVES) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
@@ -219,7 +221,14 @@ traceKernel(LaunchParams p, int depth)
           {
             slot = poolBase + rank;
             float4 o, d;
-            if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; state = ST_HAS_RAY; }
+            if (PRIMARY)
+            {
+              const PrimaryRay pr = primaryRay(p, slot);
+              o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, p.sceneEpsilon);
+              d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, pr.active ? RT_DEFAULT_MAX : -1.0f);
+              state = ST_HAS_RAY;
+            }
+            else if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; state = ST_HAS_RAY; }
             else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT); }
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
@@ -476,7 +485,7 @@ traceKernel(LaunchParams p, int depth)
           if (COUNT) ++closestCount;
           if (p.firstHit != nullptr && depth == 0)
           {
-            const unsigned int pixel = p.rayPixel[q][slot];
+            const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
             p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
             p.firstHitInstance[pixel] = res.instance;
           }
@@ -533,7 +542,7 @@ traceKernel(LaunchParams p, int depth)
 // Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again
 // with the single-ray traversal whose stack continues in HBM. Launched behind every traceKernel; exits at once when
 // the list is empty.
-template<bool COUNT, bool CUTOUT>
+template<bool COUNT, bool CUTOUT, bool PRIMARY>
 __global__ void __launch_bounds__(TWK_TRACE_BLOCK)
 traceOverflowKernel(LaunchParams p, int depth)
 {
@@ -549,8 +558,18 @@ traceOverflowKernel(LaunchParams p, int depth)
   {
     const unsigned int slot = p.overflowSlots[k];
     const bool isShadow = !(slot < numClosest);
-    const float4 o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
-    const float4 d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+    float4 o, d;
+    if (PRIMARY)
+    {
+      const PrimaryRay pr = primaryRay(p, slot);
+      o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, p.sceneEpsilon);
+      d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, pr.active ? RT_DEFAULT_MAX : -1.0f);
+    }
+    else
+    {
+      o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
+      d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+    }
     float tmin = o.w; // carries the distance of the last ignored cutout candidate, if any
     TraceResult res;
     for (;;)
@@ -565,7 +584,7 @@ traceOverflowKernel(LaunchParams p, int depth)
       p.hitInstance[slot] = res.instance;
       if (p.firstHit != nullptr && depth == 0)
       {
-        const unsigned int pixel = p.rayPixel[q][slot];
+        const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
         p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
         p.firstHitInstance[pixel] = res.instance;
       }
@@ -617,35 +636,34 @@ traceQueryKernel(LaunchParams p, const float* __restrict__ rays, unsigned int nu
   }
 }
 
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7>
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
 static void launchTraceVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
-  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
-  hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7, PRIMARY>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT, PRIMARY>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+}
+
+template<bool COUNT, bool PRIMARY>
+static void launchTraceOpaque(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
+{
+  if (p.twoLevel)                                                      launchTraceVariant<COUNT, false, true,  false, PRIMARY>(p, depth, gridBlocks, stream);
+  else if (p.traceWaves == TWK_TRACE_WAVES7 && !(PRIMARY && TWK_PRIMARY_SIX)) launchTraceVariant<COUNT, false, false, true,  PRIMARY>(p, depth, gridBlocks, stream);
+  else                                         launchTraceVariant<COUNT, false, false, false, PRIMARY>(p, depth, gridBlocks, stream);
 }
 
 // gridBlocks must be numCUs x p.traceWaves (or a lane's share of it): every block of the persistent kernel resident at once.
-void launchTrace(const LaunchParams& p, int depth, bool count, int gridBlocks, hipStream_t stream)
+// primary: depth 0 of a pass whose generateKernel was skipped (no cutout opacity in the scene).
+void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream)
 {
-  if (p.traceWaves == TWK_TRACE_WAVES7 && !p.hasCutout && !p.twoLevel)
+  if (!p.hasCutout)
   {
-    if (count) launchTraceVariant<true,  false, false, true>(p, depth, gridBlocks, stream);
-    else       launchTraceVariant<false, false, false, true>(p, depth, gridBlocks, stream);
+    if (primary) { if (count) launchTraceOpaque<true, true>(p, depth, gridBlocks, stream);  else launchTraceOpaque<false, true>(p, depth, gridBlocks, stream); }
+    else         { if (count) launchTraceOpaque<true, false>(p, depth, gridBlocks, stream); else launchTraceOpaque<false, false>(p, depth, gridBlocks, stream); }
     return;
   }
-  const int variant = (count ? 4 : 0) | (p.hasCutout ? 2 : 0) | (p.twoLevel ? 1 : 0);
-  switch (variant)
-  {
-    case 0: launchTraceVariant<false, false, false, false>(p, depth, gridBlocks, stream); break;
-    case 1: launchTraceVariant<false, false, true,  false>(p, depth, gridBlocks, stream); break;
-    case 2: launchTraceVariant<false, true,  false, false>(p, depth, gridBlocks, stream); break;
-    case 3: launchTraceVariant<false, true,  true,  false>(p, depth, gridBlocks, stream); break;
-    case 4: launchTraceVariant<true,  false, false, false>(p, depth, gridBlocks, stream); break;
-    case 5: launchTraceVariant<true,  false, true,  false>(p, depth, gridBlocks, stream); break;
-    case 6: launchTraceVariant<true,  true,  false, false>(p, depth, gridBlocks, stream); break;
-    default: launchTraceVariant<true, true,  true,  false>(p, depth, gridBlocks, stream); break;
-  }
+  if (p.twoLevel) { if (count) launchTraceVariant<true, true, true,  false, false>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, true,  false, false>(p, depth, gridBlocks, stream); }
+  else            { if (count) launchTraceVariant<true, true, false, false, false>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, false, false, false>(p, depth, gridBlocks, stream); }
 }
 
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream)
