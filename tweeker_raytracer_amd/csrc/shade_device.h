@@ -350,10 +350,19 @@ struct LightSampleD
 };
 
 // ENV: the scene has the importance-sampled spherical environment (miss 2); compiled out of the kernel variant of scenes without it.
-template<bool ENV>
-TWK_D void sampleLight(const LaunchParams& p, int index, const V3& point, float sx, float sy, LightSampleD& ls)
+// Where shading reads the instance / material / light records: the scene's arrays, or a block's copies of them in LDS
+// (shade_kernels.hip shadeKernel).
+struct ShadeTables
 {
-  const DevLight& light = p.lights[index];
+  const DevInstance* instances;
+  const DevMaterial* materials;
+  const DevLight*    lights;
+};
+
+template<bool ENV>
+TWK_D void sampleLight(const LaunchParams& p, const ShadeTables& tables, int index, const V3& point, float sx, float sy, LightSampleD& ls)
+{
+  const DevLight& light = tables.lights[index];
   if (light.type == 1) // light_sample.cu:156-177 parallelogram
   {
     ls.pdf = 0.0f;
@@ -465,7 +474,7 @@ struct ShadeOutput
 // PRIMARY: the first segment of a path whose generateKernel was skipped (shade_kernels.hip "primary rays"): this call owns the
 // path's radiance and AOV words and initialises them (raygeneration.cu:53-62) instead of adding to them.
 template<bool ENV = true, bool TEX = true, bool PRIMARY = false>
-TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const float4& ro, const float4& rd,
+TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth, unsigned int pixel, const float4& ro, const float4& rd,
                      const float4& hit, int instanceIndex, ShadeOutput& out)
 {
   if (PRIMARY && p.pathAlbedo != nullptr)
@@ -540,13 +549,13 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   else
   {
     // ---- __closesthit__radiance, closesthit.cu:126-305
-    const DevInstance& inst = p.instances[instanceIndex];
+    const DevInstance& inst = tables.instances[instanceIndex];
     // The slot's shading record (bvh_build.hip emitTrianglesKernel): geometric normal and vertex normals for every
     // hit; tangents and texture coordinates are fetched only by the materials that read them (the tangent feeds the
     // GGX tangent space only, closesthit.cu:161 computes it for all) — each fetch is one divergent lane address.
     const float4* sv = p.shadeTriangles + TWK_SHADE_RECORD * (size_t) __float_as_int(hit.w);
     const float4 s0 = sv[0], s1 = sv[1], s2 = sv[2];
-    const DevMaterial& material = p.materials[inst.material];
+    const DevMaterial& material = tables.materials[inst.material];
     const bool needTangent  = material.indexBSDF >= 3;
     const bool needTexcoord = TEX && material.textureAlbedo != 0;
 
@@ -595,7 +604,7 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
       const float cosTheta = dot(prd.wo, state.normalGeo);
       if ((prd.flags & TWK_FLAG_FRONTFACE) && DENOMINATOR_EPSILON < cosTheta)
       {
-        const DevLight& light = p.lights[inst.light];
+        const DevLight& light = tables.lights[inst.light];
         emission = v3(light.emission[0], light.emission[1], light.emission[2]);
         const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
         if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
@@ -614,7 +623,7 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
       const float cosTheta = dot(prd.wo, state.normalGeo);
       if (DENOMINATOR_EPSILON < cosTheta)
       {
-        const DevLight& light = p.lights[inst.light];
+        const DevLight& light = tables.lights[inst.light];
         V3 emission = v3(light.emission[0], light.emission[1], light.emission[2]);
         const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
         if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
@@ -653,7 +662,7 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
         const int lightIndex = (1 < numLights) ? min(max(static_cast<int>(floorf(rng(prd.seed) * numLights)), 0), numLights - 1) : 0;
 
         LightSampleD ls;
-        sampleLight<ENV>(p, lightIndex, prd.pos, sx, sy, ls);
+        sampleLight<ENV>(p, tables, lightIndex, prd.pos, sx, sy, ls);
 
         if (0.0f < ls.pdf)
         {
@@ -761,6 +770,16 @@ TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const
   }
   out.alive = alive;
   out.nextPos = prd.pos; out.nextDir = prd.wi;
+}
+
+// The same with the records read from the scene's arrays (tail kernel, host build of the kernels).
+template<bool ENV = true, bool TEX = true, bool PRIMARY = false>
+TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const float4& ro, const float4& rd,
+                     const float4& hit, int instanceIndex, ShadeOutput& out)
+{
+  ShadeTables tables;
+  tables.instances = p.instances; tables.materials = p.materials; tables.lights = p.lights;
+  shadePath<ENV, TEX, PRIMARY>(p, tables, depth, pixel, ro, rd, hit, instanceIndex, out);
 }
 
 // ---------------------------------------------------------------------------------------------

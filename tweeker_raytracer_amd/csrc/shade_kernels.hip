@@ -102,10 +102,16 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 // the seed, two draws, the lens shader) — PRIMARY variants of traceKernel and shadeKernel, launched at depth 0 — and the first
 // shade launch writes the path's radiance instead of adding to it. device_api.hip renderPass keeps generateKernel for what
 // the fused path does not cover (cutout opacity draws from the seed IN the queue; no bounce at all).
+#ifndef TWK_SHADE_LDS_TABLES
+#define TWK_SHADE_LDS_TABLES 1
+#endif
+#ifndef TWK_SHADE_TABLE_BYTES
+#define TWK_SHADE_TABLE_BYTES 20480 // per block; five blocks per CU
+#endif
 #ifndef TWK_SHADE_WAVES_PRIMARY
 #define TWK_SHADE_WAVES_PRIMARY 4 // the PRIMARY variant carries the ray generation: 13 registers spilled at five waves
 #endif
-template<bool ENV, bool TEX, bool PRIMARY>
+template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES>
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
@@ -113,6 +119,28 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
   __shared__ unsigned int blockBase[2][2];
 
+  // Instance, material and light records in LDS (scenes whose tables fit): a hit reads ~16 float4 of them, each one divergent
+  // lane address for the CU's vector memory path, which takes one per clock — the kernel's bound (rocprofv3: 0.9 lane
+  // addresses per clock and CU) — while LDS serves a wave's read of a few distinct records in 8..32 clocks
+  // (profiles/r02a_gather_probe2.txt).
+  ShadeTables tables;
+  tables.instances = p.instances; tables.materials = p.materials; tables.lights = p.lights;
+  __shared__ float4 tableStorage[LDS_TABLES ? TWK_SHADE_TABLE_BYTES / 16 : 1];
+  if (LDS_TABLES)
+  {
+    // launchShade has checked that the three tables fit. The pointers are LDS pointers at compile time: the reads of the
+    // records become ds_read (through a pointer chosen at run time they stay flat loads, which the vector memory path
+    // processes at the same one lane address per clock whether they end in LDS or not: measured, no gain at all).
+    const unsigned int nI = (unsigned int) p.numInstances * (sizeof(DevInstance) / 16), nM = (unsigned int) p.numMaterials * (sizeof(DevMaterial) / 16), nL = (unsigned int) p.numLights * (sizeof(DevLight) / 16);
+    const float4* gI = reinterpret_cast<const float4*>(p.instances); const float4* gM = reinterpret_cast<const float4*>(p.materials); const float4* gL = reinterpret_cast<const float4*>(p.lights);
+    for (unsigned int i = threadIdx.x; i < nI; i += TWK_SHADE_BLOCK) tableStorage[i] = gI[i];
+    for (unsigned int i = threadIdx.x; i < nM; i += TWK_SHADE_BLOCK) tableStorage[nI + i] = gM[i];
+    for (unsigned int i = threadIdx.x; i < nL; i += TWK_SHADE_BLOCK) tableStorage[nI + nM + i] = gL[i];
+    tables.instances = reinterpret_cast<const DevInstance*>(tableStorage);
+    tables.materials = reinterpret_cast<const DevMaterial*>(tableStorage + nI);
+    tables.lights    = reinterpret_cast<const DevLight*>(tableStorage + nI + nM);
+    __syncthreads();
+  }
   const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const int q = depth & 1, qn = q ^ 1;
   unsigned int* nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + 0];
@@ -139,7 +167,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     {
       out.throughputPdf = in.throughputPdf;
       out.seedFlags     = in.seedFlags;
-      shadePath<ENV, TEX, PRIMARY>(p, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
+      shadePath<ENV, TEX, PRIMARY>(p, tables, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
       if (p.stats != nullptr) { if (in.instanceIndex < 0) ++statMiss; else ++statHit; }
     }
     else if (PRIMARY && in.inRange) p.pathRadiance[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // inactive launch index: weight 0, as generateKernel leaves it
@@ -343,21 +371,23 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);
 }
-template<bool PRIMARY>
+template<bool PRIMARY, bool LDS_TABLES>
 static void launchShadeVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
   const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
-  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 // primary: depth 0 of a pass whose generateKernel was skipped ("primary rays" above)
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream)
 {
-  if (primary) launchShadeVariant<true>(p, depth, gridBlocks, stream);
-  else         launchShadeVariant<false>(p, depth, gridBlocks, stream);
+  const size_t tableBytes = (size_t) p.numInstances * sizeof(DevInstance) + (size_t) p.numMaterials * sizeof(DevMaterial) + (size_t) p.numLights * sizeof(DevLight);
+  const bool lds = TWK_SHADE_LDS_TABLES && tableBytes <= (size_t) TWK_SHADE_TABLE_BYTES;
+  if (primary) { if (lds) launchShadeVariant<true, true>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false>(p, depth, gridBlocks, stream); }
+  else         { if (lds) launchShadeVariant<false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false>(p, depth, gridBlocks, stream); }
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {
