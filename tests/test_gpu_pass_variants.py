@@ -1,0 +1,124 @@
+"""-m gpu: the build- and pass-level shortcuts of round 3 change no bit of any image.
+
+  * small flattened instances as direct leaves of the top level (device_api.hip twk_build)
+  * wide-node cuts chosen by expected node visits (bvh_build.hip refitKernel)
+  * seven against six resident blocks per CU of the traversal kernel (device_types.h TWK_TRACE_WAVES7)
+  * primary rays computed by the first traversal / shade launch instead of written by generateKernel
+    (shade_kernels.hip "primary rays"), with and without a tile distribution that leaves launch indices inactive
+  * the instance / material / light records read from LDS copies by shadeKernel, and from the scene's arrays when
+    the tables do not fit (a scene of 200 instances)
+
+Each knob is an environment variable read by twk_device_create; the default (everything on) is what every other
+parity test runs against the oracle, so "equal to the default" here means "equal to the oracle" there."""
+import numpy as np
+import pytest
+
+from conftest import load_app, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _render(twk, app, iterations, index=0, count=1, batch=None):
+    dev = twk.Device(ordinal=0, index=index, count=count, miss=app.info.miss)
+    app.initDevice(dev, distribution=1 if count > 1 else None)
+    if batch is not None:
+        dev.setLaunchBatch(batch)
+    for it in range(iterations):
+        dev.render(it)
+    out = dev.getOutputBufferHost().copy()
+    info = dev.buildInfo()
+    dev.close()
+    return out, info
+
+
+KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0")]
+
+
+@pytest.mark.parametrize("system,scene,res", [
+    ("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (160, 90)),
+    ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", (128, 72)),
+    ("system_rtigo3_geometry.txt", "scene_rtigo3_geometry.txt", (128, 72)),
+])
+def test_shortcuts_change_no_bit(twk, monkeypatch, system, scene, res):
+    app = load_app(twk, system, scene, res)
+    base, info = _render(twk, app, 3)
+    assert np.isfinite(base).all() and base[..., :3].max() > 0.2
+    for name, value in KNOBS:
+        monkeypatch.setenv(name, value)
+        other, other_info = _render(twk, app, 3)
+        monkeypatch.delenv(name)
+        assert np.array_equal(_bits(other), _bits(base)), f"{name}={value}: {(_bits(other) != _bits(base)).any(axis=2).sum()} pixels differ"
+        if name == "TWK_DIRECT_SMALL_LEAVES":
+            assert other_info["directLeafInstances"] == 0 and info["directLeafInstances"] > 0
+        if name == "TWK_TRACE_WAVES_RUNTIME":
+            assert other_info["traceBlocksPerCU"] == 6
+
+
+def test_build_info_names_the_direct_leaves_and_the_kernel_build(twk):
+    """Cornell box: five walls + the area light are two-triangle instances, all flattened -> the seven-block build;
+    the instances scene enters instances -> six blocks; intro_07 has cutout opacity -> six blocks."""
+    for system, scene, leaves, blocks in [("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", 6, 7),
+                                          ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", 1, 6)]:
+        app = load_app(twk, system, scene, (32, 32))
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        app.initDevice(dev)
+        info = dev.buildInfo()
+        assert info["directLeafInstances"] == leaves, info
+        assert info["traceBlocksPerCU"] == blocks, info
+        dev.close()
+
+
+@pytest.mark.parametrize("count,index", [(3, 1), (8, 5)])
+def test_fused_primary_rays_with_inactive_launch_indices(twk, monkeypatch, count, index):
+    """A device of a tile distribution whose launch width reaches beyond the image: the launch indices without a pixel
+    are skipped by the fused path exactly as generateKernel marks them (weight 0 in the running mean), over several
+    iterations and one pass per iteration as well as one pass for all."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (200, 64))  # 25 tiles of 8 over 3 / 8 devices: ragged
+    results = []
+    for fused in ("1", "0"):
+        for batch in (1, 4):
+            monkeypatch.setenv("TWK_FUSED_PRIMARY", fused)
+            out, _ = _render(twk, app, 4, index=index, count=count, batch=batch)
+            results.append(out)
+    monkeypatch.delenv("TWK_FUSED_PRIMARY")
+    assert np.isfinite(results[0]).all() and results[0][..., :3].max() > 0.2
+    for other in results[1:]:
+        assert np.array_equal(_bits(other), _bits(results[0]))
+
+
+def _many_instances_scene(n_side):
+    lines = ["albedo 0.7 0.7 0.7", "material default brdf_diffuse", "albedo 0.5 0.5 0.5", "material floor brdf_diffuse"]
+    for k in range(6):
+        lines += [f"albedo {0.3 + 0.1 * k:.2f} {0.9 - 0.1 * k:.2f} 0.4", f"material m{k} " + ("brdf_diffuse" if k % 2 == 0 else "brdf_specular")]
+    lines += ["push", "scale 12 1 12", "model plane 1 1 1 floor", "pop"]
+    for j in range(n_side):
+        for i in range(n_side):
+            lines += ["push", "scale 0.3 0.3 0.3", f"translate {1.2 * i - 0.6 * (n_side - 1):.3f} 0.3 {1.2 * j - 0.6 * (n_side - 1):.3f}",
+                      ("model sphere 24 12 1.0 " if (i + j) % 2 else "model box ") + f"m{(i * 7 + j) % 6}", "pop"]
+    return "\n".join(lines) + "\n"
+
+
+def test_tables_beyond_the_lds_budget_use_the_scene_arrays(twk, orc):
+    """197 instances x 128 B + materials + lights > 20 KiB: shadeKernel reads the records from the scene's arrays (the
+    <.., LDS_TABLES = false> builds); 26 instances: from LDS. Both bit-identical to the oracle."""
+    system = "\n".join(["resolution 96 54", "tileSize 8 8", "samplesSqrt 1", "miss 1", "light 0", "pathLengths 2 4", "epsilonFactor 500",
+                        "lensShader 0", "center 0 0.5 0", "camera 0.75 0.6 50 16"]) + "\n"
+    for n_side, fits in ((14, False), (5, True)):
+        app = twk.Application(system_text=system, scene_text=_many_instances_scene(n_side))
+        assert (len(app.instances) * 128 + 64 * 16 <= 20480) == fits
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        ref = orc.Oracle(miss=app.info.miss)
+        app.initDevice(dev)
+        ref.loadApplication(app)
+        for it in range(2):
+            dev.render(it)
+            ref.render(it)
+        gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+        assert cpu[..., :3].max() > 0.3 and np.isfinite(cpu).all()
+        mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+        assert mism == 0, f"{n_side}x{n_side}: {mism} pixels differ"
+        dev.close()
