@@ -339,7 +339,8 @@ def main():
         # peak = HBM spec. On a scene that lives in the caches these bytes are served by LDS / L1 / L2, so `frac` can pass 1:
         # it then says "not HBM-bound", nothing more. What does bound the kernel, and the HBM-side bytes, are stated beside it.
         result["roofline"] = {
-            "kernel": "twk::traceKernel<false, false, %s, %s>" % ("true" if st["instancesEntered"] else "false", "true" if bi["traceBlocksPerCU"] == 7 else "false"),
+            "kernel": "twk::traceKernel<false, false, %s, %s, false>" % ("true" if st["instancesEntered"] else "false", "true" if bi["traceBlocksPerCU"] == 7 else "false"),
+            "kernel_note": "template arguments: COUNT, CUTOUT, TWO_LEVEL, W7 (seven resident blocks per CU), PRIMARY; the first of a pass's launches is the <.., false, true> build, which computes the primary rays instead of fetching them",
             "trace_blocks_per_cu": int(bi["traceBlocksPerCU"]),
             "bound": "hbm",
             "achieved": algo_gbps,

@@ -9,7 +9,9 @@ import sys
 
 
 def short(name):
-    for k in ("traceKernel<false, false, false, true>", "traceKernel<false, false, false, false>", "traceKernel<false, false, true", "traceKernel<false, true", "traceKernel<true", "shadeKernel", "generateKernel", "accumulateKernel"):
+    if "traceKernel<" in name:
+        return name[name.index("traceKernel<"):name.index(">", name.index("traceKernel<")) + 1]
+    for k in ("shadeKernel", "generateKernel", "accumulateKernel"):
         if k in name:
             return k
     return None
