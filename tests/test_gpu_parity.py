@@ -340,8 +340,11 @@ def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
 
 
 @pytest.mark.parametrize("scene_file,two_level", [("scene_rtigo3_cornell_box.txt", False), ("scene_rtigo3_instances.txt", True)])
-def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, scene_file, two_level):
-    """The single-threaded host walker of the test tooling (oracle/same_bvh_walk.cpp) walks the tree the DEVICE built
+def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, monkeypatch, scene_file, two_level):
+    """(Primary rays start at their tile's entry points since round 3 and visit fewer nodes than a walk from the root: the
+    walker's counts are compared with the kernel's with that shortcut off, TWK_TILE_ENTRIES=0; the hit records with it on
+    are compared in tests/test_gpu_pass_variants.py.)
+    The single-threaded host walker of the test tooling (oracle/same_bvh_walk.cpp) walks the tree the DEVICE built
     (twk_debug_read_acceleration) with the persistent kernel's per-ray algorithm: its hit records equal the device's
     bit for bit and its visit counts equal the counting kernel's (counts from the CPU running the same
     BVH on the same rays). Primary rays only: no lights, black miss, one segment."""
@@ -349,6 +352,7 @@ def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, scene_file, two_le
     system = "\n".join(["resolution 64 40", "tileSize 8 8", "samplesSqrt 1", "miss 0", "light 0", "pathLengths 1 1", "epsilonFactor 500",
                         "lensShader 0", "center 0 1 0", "camera 0.75 0.5 45 3.41" if not two_level else "camera 0.75 0.55 50 14"]) + "\n"
     app = twk.Application(system_text=system, scene_text=open(scene_path(scene_file)).read())
+    monkeypatch.setenv("TWK_TILE_ENTRIES", "0")
     dev = twk.Device(ordinal=0, miss=app.info.miss)
     app.initDevice(dev)
     acc = dev.readAcceleration()

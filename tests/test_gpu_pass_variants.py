@@ -7,6 +7,9 @@
     (shade_kernels.hip "primary rays"), with and without a tile distribution that leaves launch indices inactive
   * the instance / material / light records read from LDS copies by shadeKernel, and from the scene's arrays when
     the tables do not fit (a scene of 200 instances)
+  * primary rays starting at their tile's entry points instead of at the root (trace_kernels.hip tileEntryKernel):
+    first-hit records and images, frames that are no multiple of the tile, cameras close to and inside geometry,
+    a camera moved between launches
 
 Each knob is an environment variable read by twk_device_create; the default (everything on) is what every other
 parity test runs against the oracle, so "equal to the default" here means "equal to the oracle" there."""
@@ -35,7 +38,7 @@ def _render(twk, app, iterations, index=0, count=1, batch=None):
     return out, info
 
 
-KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0")]
+KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0"), ("TWK_TILE_ENTRIES", "0")]
 
 
 @pytest.mark.parametrize("system,scene,res", [
@@ -122,3 +125,66 @@ def test_tables_beyond_the_lds_budget_use_the_scene_arrays(twk, orc):
         mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
         assert mism == 0, f"{n_side}x{n_side}: {mism} pixels differ"
         dev.close()
+
+
+def _first_hits(twk, app, iterations=1):
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    dev.debugCapture(True)
+    for it in range(iterations):
+        dev.render(it)
+    tbg, ids = dev.debugReadFirstHits()
+    out = dev.getOutputBufferHost().copy()
+    dev.close()
+    return tbg.copy(), ids.copy(), out
+
+
+@pytest.mark.parametrize("scene,camera,res", [
+    ("scene_rtigo3_cornell_box.txt", "camera 0.75 0.5 45 3.41", (203, 117)),    # no multiple of 8 either way
+    ("scene_rtigo3_cornell_box.txt", "camera 0.1 0.5 100 0.9", (160, 96)),      # wide angle from inside the room, between the spheres
+    ("scene_rtigo3_cornell_box.txt", "camera 0.75 0.93 60 1.5", (96, 160)),     # looking down, portrait frame
+    ("scene_rtigo3_geometry.txt", "camera 0.8 0.45 60 9", (192, 108)),          # open scene: tiles of sky only
+    ("scene_rtigo3_instances.txt", "camera 0.75 0.55 50 14", (192, 108)),       # two-level: instance leaves in the lists
+    ("scene_rtigo3_instances.txt", "camera 0.3 0.52 90 1.2", (128, 128)),       # inside the grid of instances
+])
+def test_tile_entry_points_change_no_first_hit(twk, monkeypatch, scene, camera, res):
+    """The first hit of every pixel (distance, barycentrics, primitive, instance) and the image with the primary rays
+    starting at their tile's entry points equal those with every ray starting at the root, bit for bit."""
+    system = "\n".join([f"resolution {res[0]} {res[1]}", "tileSize 8 8", "samplesSqrt 1", "miss 1", "light 0", "pathLengths 2 3", "epsilonFactor 500",
+                        "lensShader 0", "center 0 1 0", camera]) + "\n"
+    app = twk.Application(system_text=system, scene_text=open(scene_path(scene)).read())
+    on = _first_hits(twk, app, 2)
+    monkeypatch.setenv("TWK_TILE_ENTRIES", "0")
+    off = _first_hits(twk, app, 2)
+    monkeypatch.delenv("TWK_TILE_ENTRIES")
+    assert np.array_equal(on[1], off[1]), f"{(on[1] != off[1]).any(axis=1).sum()} first hits differ"
+    assert np.array_equal(_bits(on[0]), _bits(off[0]))
+    assert np.array_equal(_bits(on[2]), _bits(off[2]))
+    assert (on[1][:, 0] >= 0).mean() > 0.3
+
+
+def test_tile_entry_points_follow_the_camera(twk, monkeypatch):
+    """The lists are rebuilt when the camera moves between launches (and only then): every view equals the one rendered
+    with the lists off."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (160, 90))
+    views = [(0.75, 0.5, 45.0, 3.41), (0.6, 0.4, 60.0, 2.5), (0.9, 0.7, 30.0, 3.0)]
+
+    def run():
+        dev = twk.Device(ordinal=0, miss=app.info.miss)
+        app.initDevice(dev)
+        outs = []
+        for phi, theta, fov, distance in views:
+            dev.updateCamera(0, twk.camera_frustum((0.0, 1.0, 0.0), phi, theta, fov, distance, 160 / 90))
+            for it in range(2):
+                dev.render(it)
+            outs.append(dev.getOutputBufferHost().copy())
+        dev.close()
+        return outs
+
+    on = run()
+    monkeypatch.setenv("TWK_TILE_ENTRIES", "0")
+    off = run()
+    monkeypatch.delenv("TWK_TILE_ENTRIES")
+    for a, b in zip(on, off):
+        assert np.array_equal(_bits(a), _bits(b))
+    assert not np.array_equal(_bits(on[0]), _bits(on[1]))

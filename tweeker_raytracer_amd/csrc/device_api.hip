@@ -29,6 +29,7 @@ void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int num
 void launchGenerate(const LaunchParams& p, hipStream_t stream);
 void launchTail(const LaunchParams& p, int depth0, bool count, int gridBlocks, hipStream_t stream);
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream);
+void launchTileEntries(const LaunchParams& p, const float4* topTable, int tilesX, int tilesY, int4* out, hipStream_t stream);
 void launchAccumulate(const LaunchParams& p, hipStream_t stream);
 void launchCompositor(const float4* tiles, float4* output, int width, int height, int launchWidth, int deviceCount,
                       int tileSizeX, int tileShiftX, int tileShiftY, hipStream_t stream);
@@ -104,7 +105,9 @@ struct TwkDevice_t
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
-  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
+  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ bool tileEntries = true; /* TWK_TILE_ENTRIES=0: A/B */
+  int4* d_tileEntries = nullptr; size_t tileEntriesCapacity = 0; std::vector<float> tileEntriesKey; unsigned int buildSerial = 0; // entry points of the primary rays (trace_kernels.hip tileEntryKernel) and what they were built for
+  float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
   int tlasRoot = 0;
@@ -559,6 +562,36 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   int wavefrontDepth = maxDepth;
   if (dev->tailDepth > 0 && dev->tailDepth < maxDepth) wavefrontDepth = dev->tailDepth;
 
+  // Primary rays are computed by the first traversal and the first shade launch instead of being written by generateKernel and
+  // read back (shade_kernels.hip "primary rays") — unless the scene has cutout opacity (its draws come from the seed IN the
+  // queue) or the paths have no bounce to be shaded in.
+  const bool fusedPrimary = dev->fusedPrimary && wavefrontDepth >= 1 && !p.hasCutout;
+  // ... and start at their tile's entry points (trace_kernels.hip tileEntryKernel): pinhole camera, launch index = pixel.
+  // The lists depend on camera, frame and tree; rebuilt (one small kernel) when any of those changed since they were made.
+  p.tileEntries = nullptr; p.tilesX = 0;
+  if (fusedPrimary && dev->tileEntries && p.lensShader == 0 && !(p.distribution && 1 < p.deviceCount) && p.launchWidth == p.resolution[0] && !dev->cameras.empty())
+  {
+    const int tilesX = (p.resolution[0] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE, tilesY = (p.resolution[1] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE;
+    const size_t need = (size_t) tilesX * tilesY * 2;
+    std::vector<float> key(reinterpret_cast<const float*>(&dev->cameras[0]), reinterpret_cast<const float*>(&dev->cameras[0]) + 12);
+    key.push_back((float) p.resolution[0]); key.push_back((float) p.resolution[1]); key.push_back((float) dev->buildSerial); key.push_back((float) p.topRoot);
+    if (need > dev->tileEntriesCapacity)
+    {
+      freeDevice(dev->d_tileEntries); dev->tileEntriesCapacity = 0; dev->tileEntriesKey.clear();
+      HIP_TRY(hipMalloc(&dev->d_tileEntries, sizeof(int4) * need));
+      dev->tileEntriesCapacity = need;
+    }
+    if (key != dev->tileEntriesKey)
+    {
+      // the table the PRIMARY build of the traversal kernel caches: TWK_PRIMARY_SIX -> the six-block build's
+      const float4* topTable = (TWK_PRIMARY_SIX || p.traceWaves != TWK_TRACE_WAVES7) ? p.topNodes : p.topNodes7;
+      launchTileEntries(p, topTable, tilesX, tilesY, dev->d_tileEntries, dev->stream);
+      HIP_TRY(hipGetLastError());
+      dev->tileEntriesKey = key;
+    }
+    p.tileEntries = dev->d_tileEntries; p.tilesX = tilesX;
+  }
+
   if (lanes > 1)
   {
     if (!dev->laneFork) HIP_TRY(hipEventCreateWithFlags(&dev->laneFork, hipEventDisableTiming));
@@ -589,10 +622,6 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
     if (grid > dev->numCUs * TWK_SHADE_BLOCKS_PER_CU) grid = dev->numCUs * TWK_SHADE_BLOCKS_PER_CU;
     laneP[active] = q; laneS[active] = stream; shadeGrid[active] = grid; ++active;
   }
-  // Primary rays are computed by the first traversal and the first shade launch instead of being written by generateKernel and
-  // read back (shade_kernels.hip "primary rays") — unless the scene has cutout opacity (its draws come from the seed IN the
-  // queue) or the paths have no bounce to be shaded in.
-  const bool fusedPrimary = dev->fusedPrimary && wavefrontDepth >= 1 && !p.hasCutout;
   for (int k = 0; k < active; ++k)
   {
     if (fusedPrimary) { const unsigned int numPaths = (unsigned int) laneP[k].numPaths; HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) laneP[k].counters, (int) numPaths, 1, laneS[k])); continue; } // length of queue 0
@@ -687,6 +716,7 @@ try
   if (const char* e = getenv("TWK_DIRECT_SMALL_LEAVES")) dev->directSmallLeaves = (atoi(e) != 0);
   if (const char* e = getenv("TWK_COSTED_CUTS")) dev->costedCuts = (atoi(e) != 0);
   if (const char* e = getenv("TWK_FUSED_PRIMARY")) dev->fusedPrimary = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_TILE_ENTRIES")) dev->tileEntries = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
@@ -709,7 +739,7 @@ try
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
   freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
-  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes); freeDevice(dev->d_topNodes7);
+  freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes); freeDevice(dev->d_topNodes7); freeDevice(dev->d_tileEntries);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
   freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
   if (dev->h_dropped) { (void) hipHostFree(dev->h_dropped); dev->h_dropped = nullptr; dev->d_dropped = nullptr; }
@@ -1159,7 +1189,7 @@ try
   dev->twoLevel = (numEntered > 0);
   dev->maxInstanceMaterial = maxMaterial; dev->maxInstanceLight = maxLight;
   dev->totalNodes = numNodes; dev->totalTriangles = numTris;
-  dev->built = true;
+  dev->built = true; ++dev->buildSerial;
   return TWK_SUCCESS;
 }
 TWK_CATCH("twk_build")
@@ -1656,6 +1686,7 @@ try
   q.envCDF_V = static_cast<const float*>(host(dev->d_envCDF_V, sizeof(float) * ((size_t) q.envHeight + 1)));
   if (rc) return twkSetError(rc, "twk_debug_snapshot_scene: device-to-host copy failed");
   // streams, counters, outputs: the host build allocates its own
+  q.tileEntries = nullptr; q.tilesX = 0;
   for (int k = 0; k < 2; ++k) { q.rayOrg[k] = nullptr; q.rayDir[k] = nullptr; q.rayPixel[k] = nullptr; q.rayThroughput[k] = nullptr; q.raySeedFlags[k] = nullptr; }
   q.hitRecord = nullptr; q.hitInstance = nullptr; q.shadowOrg = nullptr; q.shadowDir = nullptr; q.shadowPixel = nullptr; q.shadowPending = nullptr;
   q.pathRadiance = nullptr; q.volumeStack = nullptr; q.pathAlbedo = nullptr; q.pathNormal = nullptr; q.aovAlbedo = nullptr; q.aovNormal = nullptr;

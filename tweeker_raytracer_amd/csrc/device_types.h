@@ -208,6 +208,10 @@ struct LaunchParams
   int     numPaths;       // numPixels * batchCount: paths of this wavefront pass, path = sample * numPixels + launch index
   int     batchCount;     // iterations rendered together (iterationIndex .. iterationIndex + batchCount - 1)
   int     pathBase;       // first path of the pass this launch's streams start at (a pass cut into lanes, device_api.hip renderPass); 0 otherwise
+  // Entry points of the primary rays (trace_kernels.hip tileEntryKernel), nullptr when off: per tile of TWK_ENTRY_TILE x
+  // TWK_ENTRY_TILE launch indices two int4 = (count, ref 0..6): the subtrees a ray through that tile can reach, nearest first.
+  const int4* tileEntries;
+  int     tilesX;
   unsigned int* droppedPushes; // pinned host word (device-mapped): pushes the single-ray traversal could not store (trace_device.h TWK_PUSH); stays 0 on every scene twk_build accepts
 };
 
@@ -239,6 +243,8 @@ struct LaunchParams
 #ifndef TWK_TRACE_WAVES7_MAX_NODES
 #define TWK_TRACE_WAVES7_MAX_NODES 1000000 // binary nodes (= triangle slots - 1); measured on the Cornell room: +2.7 % at 64 k, +2.3 % at 258 k, +2.9 % at 977 k, -2.5 % at 2.0 M
 #endif
+#define TWK_ENTRY_TILE 8        // launch indices per side of a primary-ray entry tile
+#define TWK_ENTRY_REFS 7        // references per tile at most (with the count: two int4)
 #ifndef TWK_PRIMARY_SIX
 #define TWK_PRIMARY_SIX 1 // the PRIMARY build of the trace kernel (shade_kernels.hip "primary rays") runs six blocks per CU (2 registers spilled), not seven (16)
 #endif
