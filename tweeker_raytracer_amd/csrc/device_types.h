@@ -243,7 +243,9 @@ struct LaunchParams
 #ifndef TWK_TRACE_WAVES7_MAX_NODES
 #define TWK_TRACE_WAVES7_MAX_NODES 1000000 // binary nodes (= triangle slots - 1); measured on the Cornell room: +2.7 % at 64 k, +2.3 % at 258 k, +2.9 % at 977 k, -2.5 % at 2.0 M
 #endif
+#ifndef TWK_ENTRY_TILE
 #define TWK_ENTRY_TILE 8        // launch indices per side of a primary-ray entry tile
+#endif
 #define TWK_ENTRY_REFS 7        // references per tile at most (with the count: two int4)
 #ifndef TWK_PRIMARY_SIX
 #define TWK_PRIMARY_SIX 1 // the PRIMARY build of the trace kernel (shade_kernels.hip "primary rays") runs six blocks per CU (2 registers spilled), not seven (16)
