@@ -75,12 +75,17 @@ def test_build_info_names_the_direct_leaves_and_the_kernel_build(twk):
         dev.close()
 
 
-@pytest.mark.parametrize("count,index", [(3, 1), (8, 5)])
-def test_fused_primary_rays_with_inactive_launch_indices(twk, monkeypatch, count, index):
+@pytest.mark.parametrize("count,index,tile", [(3, 1, 8), (8, 5, 8), (2, 1, 16), (3, 0, 4)])
+def test_fused_primary_rays_with_inactive_launch_indices(twk, monkeypatch, count, index, tile):
     """A device of a tile distribution whose launch width reaches beyond the image: the launch indices without a pixel
     are skipped by the fused path exactly as generateKernel marks them (weight 0 in the running mean), over several
-    iterations and one pass per iteration as well as one pass for all."""
-    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (200, 64))  # 25 tiles of 8 over 3 / 8 devices: ragged
+    iterations and one pass per iteration as well as one pass for all. With distribution tiles of 8 and 16 the primary
+    rays also start at their entry points (an entry tile is one pixel square of a distribution tile); with tiles of 4 the
+    lists are off."""
+    import re
+    system = re.sub(r"(?m)^tileSize .*$", f"tileSize {tile} {tile}", open(scene_path("system_rtigo3_cornell_box.txt")).read())
+    system = re.sub(r"(?m)^resolution .*$", "resolution 200 64", system)  # 25 tiles of 8 over 3 / 8 devices: ragged
+    app = twk.Application(system_text=system, scene_text=open(scene_path("scene_rtigo3_cornell_box.txt")).read())
     results = []
     for fused in ("1", "0"):
         for batch in (1, 4):

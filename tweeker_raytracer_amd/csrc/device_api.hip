@@ -566,15 +566,19 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   // read back (shade_kernels.hip "primary rays") — unless the scene has cutout opacity (its draws come from the seed IN the
   // queue) or the paths have no bounce to be shaded in.
   const bool fusedPrimary = dev->fusedPrimary && wavefrontDepth >= 1 && !p.hasCutout;
-  // ... and start at their tile's entry points (trace_kernels.hip tileEntryKernel): pinhole camera, launch index = pixel.
+  // ... and start at their tile's entry points (trace_kernels.hip tileEntryKernel): pinhole camera; launch index = pixel, or a
+  // tile distribution whose tiles are whole entry tiles.
   // The lists depend on camera, frame and tree; rebuilt (one small kernel) when any of those changed since they were made.
   p.tileEntries = nullptr; p.tilesX = 0;
-  if (fusedPrimary && dev->tileEntries && p.lensShader == 0 && !(p.distribution && 1 < p.deviceCount) && p.launchWidth == p.resolution[0] && !dev->cameras.empty())
+  const bool distributed = p.distribution && 1 < p.deviceCount;
+  const bool tilesAlign = !distributed || (p.tileSize[0] % TWK_ENTRY_TILE == 0 && p.tileSize[1] % TWK_ENTRY_TILE == 0); // a distribution tile = whole entry tiles
+  if (fusedPrimary && dev->tileEntries && p.lensShader == 0 && tilesAlign && (distributed || p.launchWidth == p.resolution[0]) && !dev->cameras.empty())
   {
-    const int tilesX = (p.resolution[0] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE, tilesY = (p.resolution[1] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE;
+    const int tilesX = (p.launchWidth + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE, tilesY = (p.resolution[1] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE;
     const size_t need = (size_t) tilesX * tilesY * 2;
     std::vector<float> key(reinterpret_cast<const float*>(&dev->cameras[0]), reinterpret_cast<const float*>(&dev->cameras[0]) + 12);
     key.push_back((float) p.resolution[0]); key.push_back((float) p.resolution[1]); key.push_back((float) dev->buildSerial); key.push_back((float) p.topRoot);
+    key.push_back((float) p.launchWidth); key.push_back((float) (distributed ? p.deviceCount : 1)); key.push_back((float) p.deviceIndex); key.push_back((float) p.tileSize[0]); key.push_back((float) p.tileSize[1]);
     if (need > dev->tileEntriesCapacity)
     {
       freeDevice(dev->d_tileEntries); dev->tileEntriesCapacity = 0; dev->tileEntriesKey.clear();

@@ -707,7 +707,16 @@ __global__ void __launch_bounds__(64) tileEntryKernel(LaunchParams p, const floa
   const float* cam = p.camera;
   const V3 P = v3(cam[0], cam[1], cam[2]), U = v3(cam[3], cam[4], cam[5]), V = v3(cam[6], cam[7], cam[8]), W = v3(cam[9], cam[10], cam[11]);
   const float screenX = float(p.resolution[0]), screenY = float(p.resolution[1]);
-  const float x0 = float(tx * TWK_ENTRY_TILE) - 0.5f, x1 = fminf(float(tx * TWK_ENTRY_TILE + TWK_ENTRY_TILE), screenX) + 0.5f;
+  // the tile's pixels: its launch indices themselves, or — a device of a tile distribution — where distribute() puts them
+  // (the host has checked that a distribution tile is a whole number of entry tiles: one entry tile = one pixel square)
+  unsigned int column = (unsigned int) (tx * TWK_ENTRY_TILE);
+  if (p.distribution && 1 < p.deviceCount) column = distribute(p, column, (unsigned int) (ty * TWK_ENTRY_TILE));
+  if (column >= (unsigned int) p.resolution[0])
+  {
+    out[2 * (size_t) tile] = make_int4(0, 0, 0, 0); out[2 * (size_t) tile + 1] = make_int4(0, 0, 0, 0); // launch indices without a pixel
+    return;
+  }
+  const float x0 = float(column) - 0.5f, x1 = fminf(float(column + TWK_ENTRY_TILE), screenX) + 0.5f;
   const float y0 = float(ty * TWK_ENTRY_TILE) - 0.5f, y1 = fminf(float(ty * TWK_ENTRY_TILE + TWK_ENTRY_TILE), screenY) + 0.5f;
   auto direction = [&](float fx, float fy) { return U * ((fx / screenX) * 2.0f - 1.0f) + V * ((fy / screenY) * 2.0f - 1.0f) + W; };
   const V3 d00 = direction(x0, y0), d10 = direction(x1, y0), d01 = direction(x0, y1), d11 = direction(x1, y1);
