@@ -15,5 +15,6 @@ cp $SRC/scene_perf.jsonl $DST/${TAG}_scene_perf.jsonl
 cp $SRC/depth_profile_b64.jsonl $DST/${TAG}_depth_profile_b64.jsonl
 cp $SRC/depth_profile_b20.jsonl $DST/${TAG}_depth_profile_b20.jsonl
 cp $SRC/big_scene_probe.jsonl $DST/${TAG}_big_scene_probe.jsonl
+for n in s20 default; do t=$(find $SRC/stats_$n -name "*kernel_trace.csv" | head -1); python3 tools/step_timeline.py $t > $DST/${TAG}_pass_timeline_$n.txt; done
 cp $SRC/r03_trace_hbm_traffic_s20.json $SRC/r03_trace_hbm_traffic_s64.json $DST/
 ls $DST | grep ${TAG}_

@@ -1,14 +1,31 @@
 #!/usr/bin/env python3
-"""Print the per-kernel timeline of one step from a rocprofv3 kernel trace CSV."""
-import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1]))]
-sel = [r for r in rows if any(k in r['Kernel_Name'] for k in ('traceKernel<false', 'shadeKernel', 'generateKernel', 'accumulateKernel'))]
-gi = [i for i, r in enumerate(sel) if 'generate' in r['Kernel_Name']]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(gi) // 2
-i0, i1 = gi[k], gi[k + 1]
-t0 = int(sel[i0]['Start_Timestamp']); prev = None
-for r in sel[i0:i1]:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    print('%-28s start %8.1f dur %7.1f us gap %5.1f' % (r['Kernel_Name'][:28], (s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0))
+"""Prints the kernels of one wavefront pass in launch order — start, duration, gap to the previous kernel — from a rocprofv3
+kernel-trace CSV of `python bench.py`. A pass ends with accumulateKernel (there is no generateKernel any more on the fused
+path). usage: tools/step_timeline.py <kernel_trace.csv> [which pass: index among the passes of at least `min ms`, default the
+last but one] [min ms of kernel time of a pass, default 5]"""
+import csv
+import sys
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+floor_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 5.0
+names = ("traceKernel<", "shadeKernel", "generateKernel", "accumulateKernel", "traceOverflowKernel", "tileEntryKernel", "tailKernel")
+passes, cur = [], []
+for r in rows:
+    if any(k in r["Kernel_Name"] for k in names):
+        cur.append(r)
+        if "accumulateKernel" in r["Kernel_Name"]:
+            passes.append(cur)
+            cur = []
+big = [p for p in passes if sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in p) >= floor_ms * 1.0e6]
+p = big[int(sys.argv[2])] if len(sys.argv) > 2 else big[-2 if len(big) > 1 else -1]
+t0 = int(p[0]["Start_Timestamp"])
+prev = t0
+busy = 0
+for r in p:
+    n, s, e = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    short = n[n.index("twk::") + 5:] if "twk::" in n else n
+    short = short[:short.index("(")] if "(" in short else short
+    print("%-52s start %9.1f us  dur %8.1f us  gap %5.1f" % (short[:52], (s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3))
     prev = e
-print('step total %.1f us' % ((prev - t0) / 1e3))
+    busy += e - s
+print("pass total %.1f us, kernels %.1f us, %d launches" % ((prev - t0) / 1e3, busy / 1e3, len(p)))
