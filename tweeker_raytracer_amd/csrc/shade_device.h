@@ -727,11 +727,16 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   }
   else if (!wantShadow)
   {
-    // emission / environment (or nothing): radiance += throughput * prd.radiance
-    float4 r = p.pathRadiance[pixel];
+    // emission / environment (or nothing): radiance += throughput * prd.radiance. A segment that adds exactly zero (a specular
+    // bounce, a surface without emission) leaves the word alone: the sum starts at +0 and only takes non-negative addends,
+    // so x + 0 is x bit for bit (a NaN addend is not zero and is added).
     const V3 add = throughput * prd.radiance;
-    r.x += add.x; r.y += add.y; r.z += add.z;
-    p.pathRadiance[pixel] = r;
+    if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f)
+    {
+      float4 r = p.pathRadiance[pixel];
+      r.x += add.x; r.y += add.y; r.z += add.z;
+      p.pathRadiance[pixel] = r;
+    }
   }
 
   bool alive = !((prd.flags & TWK_FLAG_TERMINATE) || prd.pdf <= 0.0f || isNull(prd.f_over_pdf));
