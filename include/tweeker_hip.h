@@ -27,7 +27,7 @@ extern "C" {
 
 /* 3: TwkLaunchStats grew by waveCycles[6] (twk_stats_get writes sizeof(TwkLaunchStats) bytes) and
  * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
-#define TWK_ABI_VERSION 5
+#define TWK_ABI_VERSION 6
 
 typedef enum TwkResult
 {
@@ -266,6 +266,15 @@ int twk_set_shader_variant(TwkDevice dev, int variant);
 enum { TWK_AOV_ALBEDO = 0, TWK_AOV_NORMAL = 1 };
 int twk_enable_aov(TwkDevice dev, int enable);
 int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats);
+
+/* ABI 6. Time view, ≙ the reference's compile-time USE_TIME_VIEW (apps/rtigo3/shaders/config.h:60, raygeneration.cu:169-171,
+ * 231-244, Device.h:350): while enabled the ALPHA of the accumulation buffer is not 1 but the running mean of
+ * (shader-clock cycles the sample's lanes spent in traversal and shading) x TwkDeviceState::clockFactor x 1e-9 — what
+ * rtigo3's rasteriser maps through its colour ramp. RGB is unchanged, bit for bit. The reference counts one thread's
+ * clock() from ray generation to the write; a wavefront path has no single thread, so the cycles of its lanes in every
+ * traversal and shade launch are summed (lanes of a wave wait for each other in both designs). Measurement builds of the
+ * kernels run while it is on (as with twk_stats_enable): it is a diagnostic view, not a fast path. */
+int twk_set_time_view(TwkDevice dev, int enable);
 
 /* Output. With distribution 0 the buffer is W×H (≙ outputBuffer); with distribution 1 it is the
  * packed launchWidth×H local tile buffer (≙ texelBuffer, DeviceMultiGPULocalCopy.cpp:109-172). */

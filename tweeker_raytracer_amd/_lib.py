@@ -100,7 +100,7 @@ SYMBOLS = [
     "twk_set_state", "twk_init_cameras", "twk_init_lights", "twk_init_materials", "twk_update_camera",
     "twk_update_light", "twk_update_material", "twk_init_texture", "twk_add_geometry", "twk_add_instance",
     "twk_build", "twk_clear_scene", "twk_set_flatten_policy", "twk_set_build_quality", "twk_get_build_info", "twk_launch", "twk_sync", "twk_set_launch_batch", "twk_reserve_launch_batch", "twk_get_launch_width", "twk_read_output",
-    "twk_set_shader_variant", "twk_enable_aov", "twk_read_aov", "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_set_shared_frame", "twk_compositor", "twk_tonemap", "twk_profile_enable",
+    "twk_set_shader_variant", "twk_enable_aov", "twk_read_aov", "twk_set_time_view", "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_set_shared_frame", "twk_compositor", "twk_tonemap", "twk_profile_enable",
     "twk_profile_reset", "twk_profile_get", "twk_stats_enable", "twk_stats_get", "twk_stream_peak_gbps", "twk_gather_peak",
     "twk_debug_capture", "twk_debug_read_first_hits", "twk_trace_rays", "twk_debug_trace_queue", "twk_debug_read_acceleration", "twk_debug_snapshot_scene", "twk_debug_math",
     "twk_app_create", "twk_app_create_from_strings", "twk_app_destroy", "twk_app_info", "twk_app_set_resolution",

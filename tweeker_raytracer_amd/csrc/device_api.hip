@@ -126,6 +126,7 @@ struct TwkDevice_t
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
   // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
   bool aovEnabled = false; int shaderVariant = TWK_SHADERS_RTIGO3;
+  bool timeView = false; float* d_pathTime = nullptr; int timePaths = 0; // twk_set_time_view
   float4* d_pathAlbedo = nullptr; float4* d_pathNormal = nullptr; int aovPaths = 0;
   float4* d_aovAlbedo = nullptr; float4* d_aovNormal = nullptr; int aovPixels = 0;
   bool captureFirstHits = false;
@@ -268,7 +269,8 @@ static void refreshParams(TwkDevice dev)
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   p.outputFrame = (dev->d_outputExternal && dev->outputFrame) ? 1 : 0;
   p.counters = dev->d_counters;
-  p.stats = dev->statsEnabled ? dev->d_stats : nullptr;
+  p.stats = (dev->statsEnabled || dev->timeView) ? dev->d_stats : nullptr; // the time view runs the measurement builds of the kernels, which tally
+  p.pathTime = dev->timeView ? dev->d_pathTime : nullptr; p.clockScale = dev->state.clockFactor * 1.0e-9f; // Device.h:350 CLOCK_FACTOR_SCALE
   p.shaderVariant = dev->shaderVariant;
   p.pathAlbedo = dev->aovEnabled ? dev->d_pathAlbedo : nullptr; p.pathNormal = dev->aovEnabled ? dev->d_pathNormal : nullptr;
   p.aovAlbedo  = dev->aovEnabled ? dev->d_aovAlbedo : nullptr;  p.aovNormal  = dev->aovEnabled ? dev->d_aovNormal : nullptr;
@@ -312,6 +314,12 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
       return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "path streams of " + std::to_string(bytes >> 20) + " MiB exceed TWK_STREAM_BUDGET_MB");
     HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
     dev->allocatedPaths = numPaths;
+  }
+  if (dev->timeView && dev->allocatedPaths > dev->timePaths)
+  {
+    freeDevice(dev->d_pathTime); dev->timePaths = 0;
+    HIP_TRY(hipMalloc(&dev->d_pathTime, (size_t) dev->allocatedPaths * sizeof(float)));
+    dev->timePaths = dev->allocatedPaths;
   }
   if (dev->aovEnabled)
   {
@@ -535,6 +543,7 @@ static LaunchParams laneParams(TwkDevice dev, const LaunchParams& p, int lane, i
   q.pathRadiance += base; q.overflowSlots += 2 * base;
   q.volumeStack += 4 * base; // [4][numPaths of the lane], indexed level * numPaths + path (shade_device.h)
   if (q.pathAlbedo) { q.pathAlbedo += base; q.pathNormal += base; }
+  if (q.pathTime) q.pathTime += base;
   q.counters = dev->d_counters + (size_t) lane * TWK_COUNTER_WORDS;
   q.traceStackSpill = dev->d_spill + (size_t) lane * traceBlocks * TWK_TRACE_BLOCK * TWK_TRACE_STACK_SPILL;
   return q;
@@ -596,6 +605,8 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
     p.tileEntries = dev->d_tileEntries; p.tilesX = tilesX;
   }
 
+  if (p.pathTime != nullptr) HIP_TRY(hipMemsetAsync(p.pathTime, 0, sizeof(float) * (size_t) p.numPaths, dev->stream)); // before the fork: every lane's launches are behind it
+
   if (lanes > 1)
   {
     if (!dev->laneFork) HIP_TRY(hipEventCreateWithFlags(&dev->laneFork, hipEventDisableTiming));
@@ -636,13 +647,13 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
     const bool primary = fusedPrimary && depth == 0;
     // (the PRIMARY build of the traversal kernel needs more registers than seven blocks per CU leave: six at most)
     const int grid = (primary && TWK_PRIMARY_SIX) ? std::min(traceGrid, dev->numCUs * std::max(1, TWK_TRACE_WAVES / lanes)) : traceGrid;
-    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], depth, dev->statsEnabled, primary, grid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], depth, dev->statsEnabled || dev->timeView, primary, grid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
     for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_SHADE, laneS[k]); launchShade(laneP[k], depth, primary, shadeGrid[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
   if (maxDepth > 0)
   {
     // closest hits of queue `wavefrontDepth` (empty when wavefrontDepth == maxDepth) + the shadow rays of the last shade
-    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], wavefrontDepth, dev->statsEnabled, false, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
+    for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], wavefrontDepth, dev->statsEnabled || dev->timeView, false, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
   if (wavefrontDepth < maxDepth)
   {
@@ -745,7 +756,7 @@ try
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
   freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes); freeDevice(dev->d_topNodes7); freeDevice(dev->d_tileEntries);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
-  freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill);
+  freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill); freeDevice(dev->d_pathTime);
   if (dev->h_dropped) { (void) hipHostFree(dev->h_dropped); dev->h_dropped = nullptr; dev->d_dropped = nullptr; }
   freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
   freeDevice(dev->d_pathAlbedo); freeDevice(dev->d_pathNormal); freeDevice(dev->d_aovAlbedo); freeDevice(dev->d_aovNormal);
@@ -1302,6 +1313,17 @@ try
   return TWK_SUCCESS;
 }
 TWK_CATCH("twk_enable_aov")
+
+int twk_set_time_view(TwkDevice dev, int enable)
+try
+{
+  int rc = activate(dev, "twk_set_time_view"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (enable && dev->tailDepth > 0) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_set_time_view: not available together with the tail kernel (TWK_TAIL_DEPTH)");
+  dev->timeView = (enable != 0);
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_set_time_view")
 
 int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats)
 try

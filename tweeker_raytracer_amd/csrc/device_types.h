@@ -193,6 +193,8 @@ struct LaunchParams
   float4* volumeStack;    // [4][numPaths]
   float4* pathAlbedo;     // denoiser AOVs (Optix7Gui raygeneration.cu:125-164), per path, nullptr when off: albedo of the first diffuse / light event
   float4* pathNormal;     //   camera-space shading normal of the primary hit
+  float*  pathTime;       // time view (≙ USE_TIME_VIEW, raygeneration.cu:169-171,231-244), per path, nullptr when off: shader-clock cycles the path's lanes spent in traversal and shading
+  float   clockScale;     // clockFactor * 1e-9 (Device.h:350 CLOCK_FACTOR_SCALE): cycles -> the alpha the colour ramp reads
   float4* aovAlbedo;      // their running means per launch index (raygeneration.cu:239-262)
   float4* aovNormal;
   int     shaderVariant;  // TWK_SHADERS_RTIGO3 / TWK_SHADERS_OPTIX7GUI (include/tweeker_hip.h)

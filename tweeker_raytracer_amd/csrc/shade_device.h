@@ -916,10 +916,13 @@ TWK_D void accumulateLaunchIndex(const LaunchParams& p, const unsigned int index
       const unsigned int iteration = p.iterationIndex + (unsigned int) s;
       V3 albedo = v3(0.0f), normal = v3(0.0f);
       if (aov) { albedo = v3(p.pathAlbedo[path]); normal = v3(p.pathNormal[path]); }
+      // time view (raygeneration.cu:231-244): alpha = the sample's clock cycles * clockScale, accumulated like the radiance
+      float alpha = (p.pathTime != nullptr) ? p.pathTime[path] * p.clockScale : 1.0f;
       if (0 < iteration)
       {
         const float t = 1.0f / float(iteration + 1);
         radiance = lerp(v3(dst.x, dst.y, dst.z), radiance, t);
+        if (p.pathTime != nullptr) alpha = dst.w + t * (alpha - dst.w); // lerp(dst, result, t), fourth component
         if (aov)
         {
           // Optix7Gui raygeneration.cu:243-252: same running mean; the mean normal is renormalised unless it vanished
@@ -928,7 +931,7 @@ TWK_D void accumulateLaunchIndex(const LaunchParams& p, const unsigned int index
           if (isNotNull(normal)) normal = normalize(normal);
         }
       }
-      dst = make_float4(radiance.x, radiance.y, radiance.z, 1.0f);
+      dst = make_float4(radiance.x, radiance.y, radiance.z, alpha);
       dstAlbedo = make_float4(albedo.x, albedo.y, albedo.z, 1.0f);
       dstNormal = make_float4(normal.x, normal.y, normal.z, 0.0f);
       touched = true;

@@ -111,7 +111,8 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 #ifndef TWK_SHADE_WAVES_PRIMARY
 #define TWK_SHADE_WAVES_PRIMARY 4 // the PRIMARY variant carries the ray generation: 13 registers spilled at five waves
 #endif
-template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES>
+// TIME: the time view's build (twk_set_time_view): every path's shading cycles are added to its time word.
+template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool TIME>
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
@@ -163,12 +164,14 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     ShadeOutput out;
     out.alive = false; out.wantShadow = false;
     const unsigned int pixel = in.pixel;
+    const unsigned int clockBegin = TIME ? (unsigned int) __builtin_readcyclecounter() : 0u;
     if (in.inRange && in.rd.w >= 0.0f) // else: beyond the queue, or an inactive launch index (tile column beyond the image)
     {
       out.throughputPdf = in.throughputPdf;
       out.seedFlags     = in.seedFlags;
       shadePath<ENV, TEX, PRIMARY>(p, tables, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
       if (p.stats != nullptr) { if (in.instanceIndex < 0) ++statMiss; else ++statHit; }
+      if (TIME) atomicAdd(&p.pathTime[pixel], float((unsigned int) __builtin_readcyclecounter() - clockBegin)); // the shadow ray of this path may be adding its traversal time meanwhile: atomic
     }
     else if (PRIMARY && in.inRange) p.pathRadiance[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // inactive launch index: weight 0, as generateKernel leaves it
 
@@ -371,23 +374,28 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);
 }
-template<bool PRIMARY, bool LDS_TABLES>
+template<bool PRIMARY, bool LDS_TABLES, bool TIME>
 static void launchShadeVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
   const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
-  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, TIME>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, TIME>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, TIME>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, TIME>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 // primary: depth 0 of a pass whose generateKernel was skipped ("primary rays" above)
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream)
 {
+  if (p.pathTime != nullptr) // time view: a diagnostic build, records from the scene's arrays
+  {
+    if (primary) launchShadeVariant<true, false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true>(p, depth, gridBlocks, stream);
+    return;
+  }
   const size_t tableBytes = (size_t) p.numInstances * sizeof(DevInstance) + (size_t) p.numMaterials * sizeof(DevMaterial) + (size_t) p.numLights * sizeof(DevLight);
   const bool lds = TWK_SHADE_LDS_TABLES && tableBytes <= (size_t) TWK_SHADE_TABLE_BYTES;
-  if (primary) { if (lds) launchShadeVariant<true, true>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false>(p, depth, gridBlocks, stream); }
-  else         { if (lds) launchShadeVariant<false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false>(p, depth, gridBlocks, stream); }
+  if (primary) { if (lds) launchShadeVariant<true, true, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false>(p, depth, gridBlocks, stream); }
+  else         { if (lds) launchShadeVariant<false, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false>(p, depth, gridBlocks, stream); }
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {

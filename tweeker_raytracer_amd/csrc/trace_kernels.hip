@@ -182,6 +182,7 @@ traceKernel(LaunchParams p, int depth)
   WoopConstants woop; woop.perm = 0u; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
   unsigned int guard = 0;
+  unsigned int rayClock = 0; // COUNT, time view: shader clock when this lane took its ray
 
   for (;;)
   {
@@ -243,6 +244,7 @@ traceKernel(LaunchParams p, int depth)
             setupRay(ray, org, dir);
             woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
             currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
+            if (COUNT) rayClock = (unsigned int) __builtin_readcyclecounter();
             if (PRIMARY && entryA.x > 0)
             {
               // the tile's entry points instead of the root: the first goes next, the others wait on the stack, nearest on top
@@ -503,6 +505,7 @@ traceKernel(LaunchParams p, int depth)
           p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
           p.hitInstance[slot] = res.instance;
           if (COUNT) ++closestCount;
+          if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : p.rayPixel[q][slot]], float((unsigned int) __builtin_readcyclecounter() - rayClock)); // time view: the lane's cycles from taking the ray to its result
           if (p.firstHit != nullptr && depth == 0)
           {
             const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
@@ -513,6 +516,7 @@ traceKernel(LaunchParams p, int depth)
         else
         {
           if (COUNT) ++shadowCount;
+          if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[p.shadowPixel[slot - numClosest]], float((unsigned int) __builtin_readcyclecounter() - rayClock));
           if (res.instance < 0)
           {
             // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)

@@ -117,6 +117,10 @@ class Device:
     def enableAov(self, enable=True):
         L.check(L.lib.twk_enable_aov(self._h, int(bool(enable))))
 
+    def setTimeView(self, enable=True):
+        """≙ USE_TIME_VIEW: alpha of the accumulation buffer = running mean of the sample's shader-clock cycles x clockFactor x 1e-9."""
+        L.check(L.lib.twk_set_time_view(self._h, int(bool(enable))))
+
     def readAov(self, which):
         """Denoiser AOV running means: which = 0 albedo, 1 camera-space normal; float32 [height, launchWidth, 4]."""
         h, w = self.state.resolution[1], self.launchWidth
