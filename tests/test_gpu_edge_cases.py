@@ -146,6 +146,56 @@ def test_coincident_geometry_ties_and_lds_stack_overflow(twk, orc):
     dev.close()
 
 
+def test_lds_stack_overflow_with_cutout_opacity_on_primary_rays(twk, orc):
+    """The same stack-overflowing pile of coincident triangles, every one with stochastic cutout opacity: a primary ray
+    ignores candidates (drawing from the seed the first traversal launch stored in queue 0), overflows the LDS stack and is
+    handed to traceOverflowKernel, which continues behind the candidates ignored so far with the same seed. The fused
+    first launch (no generateKernel) must give the oracle's image, and the same image as with the kernel."""
+    from procedural import cutout_slots
+    import os
+    tri = np.array([[-1.5, -1.2, 0], [1.5, -1.2, 0], [0, 1.6, 0]], np.float32)
+    ntri = 2048
+    geo = (_attrs(np.tile(tri, (ntri, 1))), np.arange(ntri * 3, dtype=np.uint32))
+    inst = [(0, IDENT, 0) for _ in range(48)]
+    cam = twk.camera_frustum((0.0, 0.0, 0.0), 0.75, 0.5, 50.0, 6.0, 48 / 32)
+    light = twk.LightDefinition()
+    light.type = 0
+    light.area = 12.566371
+    light.emission[0] = light.emission[1] = light.emission[2] = 1.0
+    mat = _material(twk)
+    mat.useCutoutTexture = 1
+    images = []
+    for fused in ("1", "0", None):
+        if fused is not None:
+            os.environ["TWK_FUSED_PRIMARY"] = fused
+        try:
+            r = twk.Device(ordinal=0, miss=1) if fused is not None else orc.Oracle(miss=1)
+        finally:
+            os.environ.pop("TWK_FUSED_PRIMARY", None)
+        r.initTexture(1, cutout_slots())
+        r.setState(_state(twk, 48, 32, 3))
+        r.initCameras([cam])
+        r.initLights([light])
+        r.initMaterials([mat])
+        r.addGeometry(*geo)
+        for g, t, m in inst:
+            r.addInstance(g, t, m)
+        r.build()
+        if fused is not None:
+            r.statsEnable(True)
+            r.statsGet(True)
+        for it in range(3):
+            r.render(it)
+        if fused is not None:
+            assert r.statsGet(True)["overflowRays"] > 0, "the scene is built to overflow the LDS stack"
+        images.append(np.array(r.getOutputBufferHost()))
+        if fused is not None:
+            r.close()
+    assert np.isfinite(images[2]).all() and images[2][..., :3].max() > 0.1
+    assert np.array_equal(_bits(images[0]), _bits(images[2])), f"fused: {(_bits(images[0]) != _bits(images[2])).any(axis=2).sum()} pixels differ from the oracle"
+    assert np.array_equal(_bits(images[1]), _bits(images[2]))
+
+
 def _random_rotation(rng):
     q = rng.normal(size=4)
     q /= np.linalg.norm(q)

@@ -572,9 +572,8 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   if (dev->tailDepth > 0 && dev->tailDepth < maxDepth) wavefrontDepth = dev->tailDepth;
 
   // Primary rays are computed by the first traversal and the first shade launch instead of being written by generateKernel and
-  // read back (shade_kernels.hip "primary rays") — unless the scene has cutout opacity (its draws come from the seed IN the
-  // queue) or the paths have no bounce to be shaded in.
-  const bool fusedPrimary = dev->fusedPrimary && wavefrontDepth >= 1 && !p.hasCutout;
+  // read back (shade_kernels.hip "primary rays") — unless the paths have no bounce to be shaded in.
+  const bool fusedPrimary = dev->fusedPrimary && wavefrontDepth >= 1;
   // ... and start at their tile's entry points (trace_kernels.hip tileEntryKernel): pinhole camera; launch index = pixel, or a
   // tile distribution whose tiles are whole entry tiles.
   // The lists depend on camera, frame and tree; rebuilt (one small kernel) when any of those changed since they were made.

@@ -76,7 +76,8 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
       in.hit = p.hitRecord[slot];
       in.instanceIndex = p.hitInstance[slot];
       in.throughputPdf = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-      in.seedFlags = make_uint2(ray.seed, 0u);
+      // a scene with cutout opacity: the first traversal stored the seed in queue 0 and its opacity tests drew from it
+      in.seedFlags = p.hasCutout ? p.raySeedFlags[0][slot] : make_uint2(ray.seed, 0u);
     }
     return;
   }
@@ -100,8 +101,9 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 // of every path, 76 bytes each, 157 MB per C2 iteration at the HBM write rate — for the first traversal and the first shade
 // launch to read back. Both now COMPUTE the primary ray of their slot (shade_device.h primaryRay: 60 integer operations for
 // the seed, two draws, the lens shader) — PRIMARY variants of traceKernel and shadeKernel, launched at depth 0 — and the first
-// shade launch writes the path's radiance instead of adding to it. device_api.hip renderPass keeps generateKernel for what
-// the fused path does not cover (cutout opacity draws from the seed IN the queue; no bounce at all).
+// shade launch writes the path's radiance instead of adding to it. A scene with cutout opacity keeps ONE word of queue 0: the
+// seed, stored by the first traversal (its opacity tests draw from it) and read by the first shade launch. device_api.hip
+// renderPass keeps generateKernel for paths without any bounce.
 #ifndef TWK_SHADE_LDS_TABLES
 #define TWK_SHADE_LDS_TABLES 1
 #endif

@@ -24,7 +24,9 @@ namespace twk {
 // was emitted (shadowPending.w, see shadePath). Returns true when the candidate is ignored; the caller then restarts
 // the traversal strictly behind it. The new tmin is written back to the ray record so that a re-trace by
 // traceOverflowKernel continues behind the same candidate.
-TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res, bool isShadow, int q, unsigned int slot, unsigned int numClosest)
+// primary: a ray of the fused first launch (PRIMARY builds): queue 0 holds its seed (stored at the refill) but no ray record —
+// the new tmin stays in the caller's register and is handed to traceOverflowKernel through the hit record (see there).
+TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res, bool isShadow, int q, unsigned int slot, unsigned int numClosest, bool primary = false)
 {
   const DevInstance& inst = p.instances[res.instance];
   const DevMaterial& material = p.materials[inst.material];
@@ -51,7 +53,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
     p.raySeedFlags[q][slot] = sf;
   }
   if (!(opacity <= draw)) return false;
-  if (isShadow) p.shadowOrg[slot - numClosest].w = res.t; else p.rayOrg[q][slot].w = res.t;
+  if (isShadow) p.shadowOrg[slot - numClosest].w = res.t; else if (!primary) p.rayOrg[q][slot].w = res.t;
   return true;
 }
 
@@ -88,7 +90,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // every leaf a triangle range; the instance entry / exit code is compiled out.
 // W7: the seven-blocks-per-CU build of the kernel (device_types.h TWK_TRACE_WAVES7): a 19-entry LDS stack, a 32-node cache.
 // PRIMARY: depth 0 of a pass without generateKernel — the lane computes the primary ray of its slot instead of fetching it
-// (shade_kernels.hip "primary rays"); never together with CUTOUT.
+// (shade_kernels.hip "primary rays"). With CUTOUT the seed is stored in queue 0 for the opacity draws.
 template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
 __global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : TWK_TRACE_WAVES) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
@@ -229,6 +231,7 @@ traceKernel(LaunchParams p, int depth)
               o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, p.sceneEpsilon);
               d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, pr.active ? RT_DEFAULT_MAX : -1.0f);
               state = ST_HAS_RAY;
+              if (CUTOUT) p.raySeedFlags[0][slot] = make_uint2(pr.seed, 0u); // the opacity test of this segment draws from the seed in the queue (cutoutIgnoresCandidate), and shade(0) takes it from there
               if (p.tileEntries != nullptr)
               {
                 const unsigned int launchIndex = (slot + (unsigned int) p.pathBase) % (unsigned int) p.numPixels;
@@ -484,15 +487,16 @@ traceKernel(LaunchParams p, int depth)
           state = (state & ~ST_RETRACE) | ST_OVERFLOWED;
           const unsigned int k = atomicAdd(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3], 1u);
           p.overflowSlots[k] = slot;
+          if (PRIMARY && CUTOUT) p.hitRecord[slot] = make_float4(tmin, 0.0f, 0.0f, 0.0f); // where the re-trace continues: behind the candidates ignored so far
         }
         if (COUNT) maxSteps = max(maxSteps, guard);
         const bool ignoredCandidate = CUTOUT && !(state & ST_OVERFLOWED) && res.instance >= 0 &&
-                                      cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest);
+                                      cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY);
         if (ignoredCandidate)
         {
           // continue strictly behind the ignored candidate: restart the traversal with tmin = its distance
           tmin = res.t;
-          res.t = isShadow ? p.shadowDir[slot - numClosest].w : p.rayDir[q][slot].w;
+          res.t = isShadow ? p.shadowDir[slot - numClosest].w : (PRIMARY ? RT_DEFAULT_MAX : p.rayDir[q][slot].w);
           res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
           setupRay(ray, org, dir);
           woopSetup(dir, woop);
@@ -594,12 +598,12 @@ traceOverflowKernel(LaunchParams p, int depth)
       o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
       d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
     }
-    float tmin = o.w; // carries the distance of the last ignored cutout candidate, if any
+    float tmin = (PRIMARY && CUTOUT) ? p.hitRecord[slot].x : o.w; // carries the distance of the last ignored cutout candidate, if any
     TraceResult res;
     for (;;)
     {
       traverse<COUNT>(p, v3(o), v3(d), tmin, d.w, isShadow && !CUTOUT, ldsStack, spill, res, nodeCount, triCount, instCount);
-      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest))) break;
+      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY))) break;
       tmin = res.t;
     }
     if (!isShadow)
@@ -677,13 +681,19 @@ static void launchTraceOpaque(const LaunchParams& p, int depth, int gridBlocks, 
 }
 
 // gridBlocks must be numCUs x p.traceWaves (or a lane's share of it): every block of the persistent kernel resident at once.
-// primary: depth 0 of a pass whose generateKernel was skipped (no cutout opacity in the scene).
+// primary: depth 0 of a pass whose generateKernel was skipped.
 void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream)
 {
   if (!p.hasCutout)
   {
     if (primary) { if (count) launchTraceOpaque<true, true>(p, depth, gridBlocks, stream);  else launchTraceOpaque<false, true>(p, depth, gridBlocks, stream); }
     else         { if (count) launchTraceOpaque<true, false>(p, depth, gridBlocks, stream); else launchTraceOpaque<false, false>(p, depth, gridBlocks, stream); }
+    return;
+  }
+  if (primary)
+  {
+    if (p.twoLevel) { if (count) launchTraceVariant<true, true, true,  false, true>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, true,  false, true>(p, depth, gridBlocks, stream); }
+    else            { if (count) launchTraceVariant<true, true, false, false, true>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, false, false, true>(p, depth, gridBlocks, stream); }
     return;
   }
   if (p.twoLevel) { if (count) launchTraceVariant<true, true, true,  false, false>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, true,  false, false>(p, depth, gridBlocks, stream); }
