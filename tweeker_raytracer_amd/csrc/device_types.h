@@ -239,6 +239,15 @@ struct LaunchParams
 // +1.7 % (64 iterations) / +2.7 % (20), C4 geometry +2.0 %, a C5 rank's share +3.7 %. The two-level and cutout variants
 // need 76..91 VGPRs and spill at 72 (C4 instances -11 %, C3 -16 %), and scenes of millions of triangles lose 2-6 % (the
 // smaller cache and stack matter there), so those keep six blocks, a 20-entry stack and 64 cached nodes.
+#ifndef TWK_TRACE_WAVES_CUTOUT
+#define TWK_TRACE_WAVES_CUTOUT 5 // blocks per CU of the builds with cutout opacity: they need 93-95 VGPRs; at six blocks (80) 17-27 were spilled — C3 trace 0.277 -> 0.230 ms/step at five
+#endif
+#ifndef TWK_TRACE_WAVES_PRIMARY
+#define TWK_TRACE_WAVES_PRIMARY TWK_TRACE_WAVES // blocks per CU of the PRIMARY builds (flattened: 80 VGPRs, 2 spilled at six)
+#endif
+#ifndef TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL
+#define TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL 5 // ... of the two-level PRIMARY build (16 spilled at six: C4 instances +1 % at five; the flattened one: no difference)
+#endif
 #define TWK_TRACE_WAVES7      7
 #define TWK_TRACE_STACK_LDS7  19
 #define TWK_TOP_NODES7        32

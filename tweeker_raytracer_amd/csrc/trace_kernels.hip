@@ -92,7 +92,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // PRIMARY: depth 0 of a pass without generateKernel — the lane computes the primary ray of its slot instead of fetching it
 // (shade_kernels.hip "primary rays"). With CUTOUT the seed is stored in queue 0 for the opacity draws.
 template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : TWK_TRACE_WAVES) // blocks per CU = waves per SIMD: device_types.h
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : (CUTOUT ? TWK_TRACE_WAVES_CUTOUT : ((PRIMARY && TWO_LEVEL) ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : (PRIMARY ? TWK_TRACE_WAVES_PRIMARY : TWK_TRACE_WAVES)))) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
   constexpr int STACK_LDS = W7 ? TWK_TRACE_STACK_LDS7 : TWK_TRACE_STACK_LDS;
