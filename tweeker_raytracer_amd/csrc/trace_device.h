@@ -54,7 +54,10 @@ TWK_D bool slabTestGrid(float ax, float ay, float az, float bx, float by, float 
   const float tn = fmaxf(fmaxf(__builtin_fmaf(qnx, ax, bx), __builtin_fmaf(qny, ay, by)), fmaxf(__builtin_fmaf(qnz, az, bz), tmin));
   const float tf = fminf(fminf(__builtin_fmaf(qfx, ax, bx), __builtin_fmaf(qfy, ay, by)), fminf(__builtin_fmaf(qfz, az, bz), tmax));
   tnear = tn;
-  return tn * 0.9999975f <= tf * 1.0000025f;
+  // the same widening as slabTest's tn * (1 - 2.5e-6) <= tf * (1 + 2.5e-6), as ONE product: tn >= tmin >= 0 here, so dividing by
+  // the left factor keeps the direction, and 1.0000051 > (1 + 2.5e-6) / (1 - 2.5e-6) keeps it conservative (four multiplies
+  // fewer per node step of the issue-bound traversal kernel)
+  return tn <= tf * 1.0000051f;
 }
 
 // Woop-Benthin-Wald ray constants. The axis permutation (kx, ky, kz) is a cyclic shift of (x, y, z) chosen by the
