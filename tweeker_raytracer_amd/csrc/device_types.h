@@ -269,7 +269,7 @@ struct LaunchParams
 #endif
 // Passes of at most this many paths are cut into two lanes (device_api.hip chooseLanes); measured on C2, DESIGN.md 2.
 #ifndef TWK_LANES2_MAX_PATHS
-#define TWK_LANES2_MAX_PATHS 9000000 // batch <= 4 of a 1920x1080 frame
+#define TWK_LANES2_MAX_PATHS 30000000 // passes of at most this many paths run as two lanes (round 3: 9 M; re-measured on the round's final kernels: +0.9 % at 20.7 M paths of C2, +1.6 % on a C5 rank's share of 20 iterations, a tie at 29 M, -2 % at 41 M)
 #endif
 #ifndef TWK_TRACE_SMALL_CHUNK
 #define TWK_TRACE_SMALL_CHUNK 64   // queue slots per chunk of a SHORT queue (fewer than TWK_TRACE_TAIL_MIN long chunks per wave), 0 = round 2's one contiguous share per wave
