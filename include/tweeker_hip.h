@@ -27,7 +27,7 @@ extern "C" {
 
 /* 3: TwkLaunchStats grew by waveCycles[6] (twk_stats_get writes sizeof(TwkLaunchStats) bytes) and
  * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
-#define TWK_ABI_VERSION 6
+#define TWK_ABI_VERSION 7
 
 typedef enum TwkResult
 {
@@ -363,6 +363,8 @@ typedef struct TwkAccelerationInfo
   int      root;      /* node index traversal starts at */
   int      twoLevel;  /* 0: every instance is flattened, no instance reference occurs */
   uint64_t numNodes, numTriangleSlots, numInstances;
+  int      root2;     /* ABI 7: the second wide node of an 8-wide root (a ray starts at `root` with `root2` on its stack), -1: none */
+  int      reserved;
 } TwkAccelerationInfo;
 int twk_debug_read_acceleration(TwkDevice dev, TwkAccelerationInfo* info, void* wideNodes, void* triangles, void* instances);
 

@@ -88,7 +88,8 @@ extern "C" {
 
 // rays: 8 floats each (o.xyz, tmin, d.xyz, tmax). out: t, beta, gamma per ray; ids: instance, primitive (-1 on a miss; any
 // hit: ids[0] = 1 if occluded). counts: [0] wide nodes visited, [1] triangles tested, [2] instances entered, [3] deepest stack.
-int orc_walk_same_bvh(const float* wideNodes, int root, const float* triangles, const float* instances,
+// root2 >= 0: the second node of an 8-wide root — a ray starts at `root` with `root2` on its stack (bvh_build.hip wideRootKernel).
+int orc_walk_same_bvh(const float* wideNodes, int root, int root2, const float* triangles, const float* instances,
                       const float* rays, uint64_t numRays, int anyHit, float* tBetaGamma, int* ids, uint64_t counts[4])
 {
   counts[0] = counts[1] = counts[2] = counts[3] = 0;
@@ -105,6 +106,7 @@ int orc_walk_same_bvh(const float* wideNodes, int root, const float* triangles, 
     Woop woop = woopWorld;
     int currentInstance = -1, node = root;
     size_t sp = 0;
+    if (root2 >= 0) stack[sp++] = root2;
     bool done = false;
     uint64_t guard = 0;
     while (!done && ++guard < (1ull << 26))

@@ -7,6 +7,7 @@
     (shade_kernels.hip "primary rays"), with and without a tile distribution that leaves launch indices inactive
   * the instance / material / light records read from LDS copies by shadeKernel, and from the scene's arrays when
     the tables do not fit (a scene of 200 instances)
+  * the root as two wide nodes of up to eight entries (bvh_build.hip wideRootKernel)
   * primary rays starting at their tile's entry points instead of at the root (trace_kernels.hip tileEntryKernel):
     first-hit records and images, frames that are no multiple of the tile, cameras close to and inside geometry,
     a camera moved between launches
@@ -38,7 +39,7 @@ def _render(twk, app, iterations, index=0, count=1, batch=None):
     return out, info
 
 
-KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0"), ("TWK_TILE_ENTRIES", "0")]
+KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0"), ("TWK_TILE_ENTRIES", "0"), ("TWK_WIDE_ROOT", "0")]
 
 
 @pytest.mark.parametrize("system,scene,res", [
@@ -59,6 +60,28 @@ def test_shortcuts_change_no_bit(twk, monkeypatch, system, scene, res):
             assert other_info["directLeafInstances"] == 0 and info["directLeafInstances"] > 0
         if name == "TWK_TRACE_WAVES_RUNTIME":
             assert other_info["traceBlocksPerCU"] == 6
+
+
+def test_wide_root_is_built_where_it_pays(twk, monkeypatch):
+    """Cornell box: the root's two large children ({floor + spheres}, {three walls}) are entered by nearly every ray — the
+    root becomes two nodes of eight entries together; with the switch off, or a scene of a single tree, one node."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (32, 32))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    info, nodes, tris, inst = dev.readAcceleration()
+    dev.close()
+    assert info["root2"] == info["root"] + 1 and info["numNodes"] == info["root2"] + 1
+    used = 0
+    for index in (info["root"], info["root2"]):
+        q = nodes[index][6:12].view(np.uint32)
+        used += sum(1 for k in range(4) if ((q[0] >> (8 * k)) & 0xff) <= ((q[3] >> (8 * k)) & 0xff))
+    assert used == 8
+    monkeypatch.setenv("TWK_WIDE_ROOT", "0")
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    info0 = dev.readAcceleration()[0]
+    dev.close()
+    assert info0["root2"] == -1 and info0["numNodes"] == info["numNodes"] - 2
 
 
 def test_build_info_names_the_direct_leaves_and_the_kernel_build(twk):

@@ -51,4 +51,7 @@ def show(index, depth):
 
 
 show(info["root"], 0)
+if info["root2"] >= 0:
+    print("second node of the 8-wide root:")
+    show(info["root2"], 0)
 dev.close()

@@ -74,7 +74,8 @@ class LaunchStats(C.Structure):
 
 
 class AccelerationInfo(C.Structure):
-    _fields_ = [("root", C.c_int), ("twoLevel", C.c_int), ("numNodes", C.c_uint64), ("numTriangleSlots", C.c_uint64), ("numInstances", C.c_uint64)]
+    _fields_ = [("root", C.c_int), ("twoLevel", C.c_int), ("numNodes", C.c_uint64), ("numTriangleSlots", C.c_uint64), ("numInstances", C.c_uint64),
+                ("root2", C.c_int), ("reserved", C.c_int)]
 
 
 class BuildInfo(C.Structure):

@@ -8,7 +8,10 @@ void launchQuantizeWide(const BvhNode* wide, float4* out, int count, hipStream_t
 
 // Copies the first numSlots (<= TWK_TOP_NODES) quantised wide nodes (breadth-first from `root`) into top[numSlots * 4] with the
 // references among them rewritten to TWK_NODE_CACHED | slot (device_types.h).
-void launchTopCache(const float4* wideQ, int root, float4* top, int numSlots, hipStream_t stream);
+void launchTopCache(const float4* wideQ, int root, int root2, float4* top, int numSlots, hipStream_t stream);
+// The root as two wide nodes of up to eight entries together (bvh_build.hip wideRootKernel): written to the full-precision wide
+// nodes firstNew, firstNew + 1 when it pays; result[0] (device) says whether.
+void launchWideRoot(BvhNode* wide, int root, int firstNew, int* result, hipStream_t stream);
 
 // Scratch-owning LBVH builder, reused for every geometry (bottom level) and for the instance level.
 class BvhBuilder

@@ -497,7 +497,7 @@ void launchQuantizeWide(const BvhNode* wide, float4* out, int count, hipStream_t
 // Top-of-tree cache (device_types.h TWK_NODE_CACHED): breadth-first from the root over the quantised wide nodes, the
 // first TWK_TOP_NODES inner nodes; references among them become TWK_NODE_CACHED | slot. One block: thread 0 walks the
 // queue, then one thread per slot copies its node and rewrites its references.
-__global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float4* __restrict__ top, int numSlots)
+__global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, int root2, float4* __restrict__ top, int numSlots)
 {
   __shared__ int queue[TWK_TOP_NODES];
   __shared__ int count;
@@ -505,6 +505,7 @@ __global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float
   {
     int n = 1;
     queue[0] = root;
+    if (root2 != TWK_BVH_SENTINEL) queue[n++] = root2; // the second half of an 8-wide root: slot 1
     for (int i = 0; i < n; ++i)
     {
       const float4* w = wideQ + 4 * (size_t) queue[i];
@@ -536,9 +537,82 @@ __global__ void topCacheKernel(const float4* __restrict__ wideQ, int root, float
   }
 }
 
-void launchTopCache(const float4* wideQ, int root, float4* top, int numSlots, hipStream_t stream)
+void launchTopCache(const float4* wideQ, int root, int root2, float4* top, int numSlots, hipStream_t stream)
 {
-  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wideQ, root, top, numSlots < TWK_TOP_NODES ? numSlots : TWK_TOP_NODES);
+  hipLaunchKernelGGL(topCacheKernel, dim3(1), dim3(64), 0, stream, wideQ, root, root2, top, numSlots < TWK_TOP_NODES ? numSlots : TWK_TOP_NODES);
+}
+
+// An 8-wide root as TWO wide nodes. Every ray takes the node step of the root and, with probability ~1 each, of the large
+// nodes right below it (Cornell box: root, {floor + spheres}, {three walls}: 2.9 steps). The entries of the root's wide node
+// are opened — largest surface area first — while the list fits eight; if what was opened would have been entered by more
+// than one ray in one on average (sum of area ratios > 1: the price of the second node step every ray now takes), the list
+// is written as two full-precision wide nodes at `firstNew` and `firstNew + 1`, inner nodes in the first (a ray starts there
+// and finds the second on its stack), and result[0] = 1. The two are quantised with all other nodes afterwards.
+__global__ void wideRootKernel(BvhNode* wide, int root, int firstNew, int* result)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float inf = __uint_as_float(0x7f800000u);
+  WideEntry e[12];
+  int n = 0;
+  auto entriesOf = [&](int node, WideEntry* out) -> int
+  {
+    const float4* p = reinterpret_cast<const float4*>(wide + 2 * (size_t) node);
+    const int refs[4] = { __float_as_int(p[0].w), __float_as_int(p[1].w), __float_as_int(p[2].w), __float_as_int(p[3].w) };
+    int m = 0;
+    for (int k = 0; k < 4; ++k)
+    {
+      const float4 lo = p[2 * k], hi = p[2 * k + 1];
+      if (lo.x == inf && hi.x == inf) continue; // emptyEntry
+      out[m].lo = make_float4(lo.x, lo.y, lo.z, 0.0f); out[m].hi = make_float4(hi.x, hi.y, hi.z, 0.0f); out[m].ref = refs[k];
+      ++m;
+    }
+    return m;
+  };
+  n = entriesOf(root, e);
+  float4 sceneLo = make_float4(inf, inf, inf, 0.0f), sceneHi = make_float4(-inf, -inf, -inf, 0.0f);
+  for (int k = 0; k < n; ++k)
+  {
+    sceneLo = make_float4(fminf(sceneLo.x, e[k].lo.x), fminf(sceneLo.y, e[k].lo.y), fminf(sceneLo.z, e[k].lo.z), 0.0f);
+    sceneHi = make_float4(fmaxf(sceneHi.x, e[k].hi.x), fmaxf(sceneHi.y, e[k].hi.y), fmaxf(sceneHi.z, e[k].hi.z), 0.0f);
+  }
+  const float sceneArea = fmaxf(wideHalfArea(sceneLo, sceneHi), 1.0e-30f);
+  float opened = 0.0f; // expected node steps per ray the opened entries stood for
+  bool closed[12] = { false, false, false, false, false, false, false, false, false, false, false, false };
+  for (int round = 0; round < 16; ++round)
+  {
+    int pick = -1; float pickArea = -1.0f;
+    for (int k = 0; k < n; ++k)
+    {
+      if (closed[k] || e[k].ref < 0 || e[k].ref == TWK_BVH_SENTINEL) continue;
+      const float a = wideHalfArea(e[k].lo, e[k].hi);
+      if (a > pickArea) { pickArea = a; pick = k; }
+    }
+    if (pick < 0) break;
+    WideEntry c[4];
+    const int m = entriesOf(e[pick].ref, c);
+    if (n - 1 + m > 8) { closed[pick] = true; continue; }
+    opened += fminf(pickArea / sceneArea, 1.0f);
+    e[pick] = e[n - 1]; closed[pick] = closed[n - 1]; --n;
+    for (int k = 0; k < m; ++k) { e[n] = c[k]; closed[n] = false; ++n; }
+  }
+  if (n <= 4 || !(opened > 1.0f)) { result[0] = 0; return; }
+  // inner nodes first (stable)
+  for (int i = 1; i < n; ++i)
+  {
+    if (e[i].ref < 0) continue;
+    int j = i;
+    while (j > 0 && e[j - 1].ref < 0) { const WideEntry t = e[j]; e[j] = e[j - 1]; e[j - 1] = t; --j; }
+  }
+  WideEntry first[4], second[4];
+  for (int k = 0; k < 4; ++k) { first[k] = e[k]; if (4 + k < n) second[k] = e[4 + k]; else emptyEntry(second[k]); }
+  writeWideNode(wide + 2 * (size_t) firstNew, first);
+  writeWideNode(wide + 2 * (size_t) (firstNew + 1), second);
+  result[0] = 1;
+}
+
+void launchWideRoot(BvhNode* wide, int root, int firstNew, int* result, hipStream_t stream)
+{
+  hipLaunchKernelGGL(wideRootKernel, dim3(1), dim3(1), 0, stream, wide, root, firstNew, result);
 }
 
 #define BVH_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)

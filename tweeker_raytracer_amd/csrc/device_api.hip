@@ -105,7 +105,7 @@ struct TwkDevice_t
   DevMaterial* d_materials = nullptr; int materialCapacity = 0;
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
-  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ bool tileEntries = true; /* TWK_TILE_ENTRIES=0: A/B */
+  bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ bool tileEntries = true; /* TWK_TILE_ENTRIES=0: A/B */ bool wideRoot = true; /* TWK_WIDE_ROOT=0: A/B */ int wideRoot1 = 0, wideRoot2 = TWK_BVH_SENTINEL; size_t wideNodesTotal = 0;
   int4* d_tileEntries = nullptr; size_t tileEntriesCapacity = 0; std::vector<float> tileEntriesKey; unsigned int buildSerial = 0; // entry points of the primary rays (trace_kernels.hip tileEntryKernel) and what they were built for
   float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
@@ -238,7 +238,8 @@ static void refreshParams(TwkDevice dev)
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
   p.topNodes = dev->d_topNodes; p.topNodes7 = dev->d_topNodes7;
-  p.topRoot = dev->topCache ? (TWK_NODE_CACHED | 0) : dev->tlasRoot;
+  p.topRoot = dev->topCache ? (TWK_NODE_CACHED | 0) : dev->wideRoot1;
+  p.topRoot2 = (dev->wideRoot2 == TWK_BVH_SENTINEL) ? TWK_BVH_SENTINEL : (dev->topCache ? (TWK_NODE_CACHED | 1) : dev->wideRoot2);
   p.twoLevel = dev->twoLevel ? 1 : 0;
   p.numInstances = (int) dev->instances.size();
   p.numLights = (int) dev->lights.size();
@@ -585,7 +586,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
     const int tilesX = (p.launchWidth + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE, tilesY = (p.resolution[1] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE;
     const size_t need = (size_t) tilesX * tilesY * 2;
     std::vector<float> key(reinterpret_cast<const float*>(&dev->cameras[0]), reinterpret_cast<const float*>(&dev->cameras[0]) + 12);
-    key.push_back((float) p.resolution[0]); key.push_back((float) p.resolution[1]); key.push_back((float) dev->buildSerial); key.push_back((float) p.topRoot);
+    key.push_back((float) p.resolution[0]); key.push_back((float) p.resolution[1]); key.push_back((float) dev->buildSerial); key.push_back((float) p.topRoot); key.push_back((float) p.topRoot2);
     key.push_back((float) p.launchWidth); key.push_back((float) (distributed ? p.deviceCount : 1)); key.push_back((float) p.deviceIndex); key.push_back((float) p.tileSize[0]); key.push_back((float) p.tileSize[1]);
     if (need > dev->tileEntriesCapacity)
     {
@@ -732,6 +733,7 @@ try
   if (const char* e = getenv("TWK_COSTED_CUTS")) dev->costedCuts = (atoi(e) != 0);
   if (const char* e = getenv("TWK_FUSED_PRIMARY")) dev->fusedPrimary = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TILE_ENTRIES")) dev->tileEntries = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_WIDE_ROOT")) dev->wideRoot = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));
@@ -1072,8 +1074,8 @@ try
   HIP_TRY(hipMalloc(&dev->d_attributes, sizeof(TwkTriangleAttributes) * numAttr));
   HIP_TRY(hipMalloc(&dev->d_indices, sizeof(unsigned int) * numIdx));
   HIP_TRY(hipMalloc(&dev->d_nodes, sizeof(BvhNode) * numNodes));
-  HIP_TRY(hipMalloc(&dev->d_wideNodes, sizeof(BvhNode) * 2 * numNodes));
-  HIP_TRY(hipMalloc(&dev->d_wideQ, sizeof(float4) * 4 * numNodes));
+  HIP_TRY(hipMalloc(&dev->d_wideNodes, sizeof(BvhNode) * 2 * (numNodes + 2))); // + the two nodes of an 8-wide root (wideRootKernel)
+  HIP_TRY(hipMalloc(&dev->d_wideQ, sizeof(float4) * 4 * (numNodes + 2)));
   HIP_TRY(hipMalloc(&dev->d_triangles, sizeof(float4) * 3 * numTris));
   HIP_TRY(hipMalloc(&dev->d_shadeTriangles, sizeof(float4) * TWK_SHADE_RECORD * numTris));
   HIP_TRY(hipMalloc(&dev->d_instances, sizeof(DevInstance) * numInstances));
@@ -1188,11 +1190,23 @@ try
                        std::to_string(TWK_TRACE_STACK_LDS + TWK_TRACE_STACK_SPILL) + " entries" + (dev->builder.quality() == TWK_BUILD_SAH ? " (try twk_set_build_quality(TWK_BUILD_LBVH))" : ""));
   }
   // the persistent trace kernel reads the quantised copy of the wide nodes; the full-precision ones were scratch
-  launchQuantizeWide(dev->d_wideNodes, dev->d_wideQ, (int) numNodes, dev->stream);
+  // the root as two wide nodes where that pays (bvh_build.hip wideRootKernel)
+  dev->wideRoot1 = dev->tlasRoot; dev->wideRoot2 = TWK_BVH_SENTINEL; dev->wideNodesTotal = numNodes;
+  if (dev->wideRoot)
+  {
+    ScopedDeviceBuffer<int> result;
+    HIP_TRY(result.allocate(1));
+    launchWideRoot(dev->d_wideNodes, dev->tlasRoot, (int) numNodes, result.ptr, dev->stream);
+    int has = 0;
+    HIP_TRY(hipMemcpyAsync(&has, result.ptr, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    if (has) { dev->wideRoot1 = (int) numNodes; dev->wideRoot2 = (int) numNodes + 1; dev->wideNodesTotal = numNodes + 2; }
+  }
+  launchQuantizeWide(dev->d_wideNodes, dev->d_wideQ, (int) dev->wideNodesTotal, dev->stream);
   if (!dev->d_topNodes) HIP_TRY(hipMalloc(&dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
   if (!dev->d_topNodes7) HIP_TRY(hipMalloc(&dev->d_topNodes7, sizeof(float4) * 4 * TWK_TOP_NODES7));
-  launchTopCache(dev->d_wideQ, dev->tlasRoot, dev->d_topNodes, TWK_TOP_NODES, dev->stream);
-  launchTopCache(dev->d_wideQ, dev->tlasRoot, dev->d_topNodes7, TWK_TOP_NODES7, dev->stream);
+  launchTopCache(dev->d_wideQ, dev->wideRoot1, dev->wideRoot2, dev->d_topNodes, TWK_TOP_NODES, dev->stream);
+  launchTopCache(dev->d_wideQ, dev->wideRoot1, dev->wideRoot2, dev->d_topNodes7, TWK_TOP_NODES7, dev->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
   freeDevice(dev->d_wideNodes);
@@ -1667,10 +1681,11 @@ try
   int rc = activate(dev, "twk_debug_read_acceleration"); if (rc) return rc;
   if (!info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_read_acceleration: NULL info");
   if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_read_acceleration: twk_build has not been called");
-  info->root = dev->tlasRoot; info->twoLevel = dev->twoLevel ? 1 : 0;
-  info->numNodes = dev->totalNodes; info->numTriangleSlots = dev->totalTriangles; info->numInstances = dev->instances.size();
+  info->root = dev->wideRoot1; info->twoLevel = dev->twoLevel ? 1 : 0;
+  info->root2 = (dev->wideRoot2 == TWK_BVH_SENTINEL) ? -1 : dev->wideRoot2; info->reserved = 0;
+  info->numNodes = dev->wideNodesTotal; info->numTriangleSlots = dev->totalTriangles; info->numInstances = dev->instances.size(); // wide nodes: the binary nodes' + the two of an 8-wide root
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, dev->d_wideQ, sizeof(float4) * 4 * dev->totalNodes, hipMemcpyDeviceToHost));
+  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, dev->d_wideQ, sizeof(float4) * 4 * dev->wideNodesTotal, hipMemcpyDeviceToHost));
   if (triangles) HIP_TRY(hipMemcpy(triangles, dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles, hipMemcpyDeviceToHost));
   if (instances) HIP_TRY(hipMemcpy(instances, dev->d_instances, sizeof(DevInstance) * dev->instances.size(), hipMemcpyDeviceToHost));
   return TWK_SUCCESS;
@@ -1696,7 +1711,7 @@ try
     return dev->hostScene.back().data();
   };
   q.nodes          = static_cast<const BvhNode*>(host(dev->d_nodes, sizeof(BvhNode) * dev->totalNodes));
-  q.wideQ          = static_cast<const float4*>(host(dev->d_wideQ, sizeof(float4) * 4 * dev->totalNodes));
+  q.wideQ          = static_cast<const float4*>(host(dev->d_wideQ, sizeof(float4) * 4 * dev->wideNodesTotal));
   q.topNodes       = static_cast<const float4*>(host(dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
   q.topNodes7      = static_cast<const float4*>(host(dev->d_topNodes7, sizeof(float4) * 4 * TWK_TOP_NODES7));
   q.triangles      = static_cast<const float4*>(host(dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles));

@@ -142,6 +142,7 @@ struct LaunchParams
   const float4*      topNodes;       // TWK_TOP_NODES x 4 float4: the cached top of the tree (device_types.h TWK_NODE_CACHED), built by twk_build
   const float4*      topNodes7;      // the same for the seven-blocks-per-CU variant: TWK_TOP_NODES7 nodes, references among THEM rewritten
   int                topRoot;        // reference the persistent kernel starts at: TWK_NODE_CACHED | 0, or tlasRoot when the cache is off
+  int                topRoot2;       // the second node of an 8-wide root (bvh_build.hip wideRootKernel), on every ray's stack at its start; TWK_BVH_SENTINEL: none
   const float4*      wideQ;          // quantised 4-ary nodes, 64 bytes = 4 float4 per inner node index (persistent trace kernel; layout above)
   const float4*      triangles;      // 3 per triangle slot: the vertices, .w of the first = primitive id, of the second = instance (world-space slots)
   const float4*      shadeTriangles; // TWK_SHADE_RECORD (8) per triangle slot, 128 B: geometric normal + the three vertices' normals | tangents | texcoords (bvh_build.hip emitTrianglesKernel)

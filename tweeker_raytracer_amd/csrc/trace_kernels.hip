@@ -247,9 +247,11 @@ traceKernel(LaunchParams p, int depth)
             setupRay(ray, org, dir);
             woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
             currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
+            if (p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; } // the root's second node (wideRootKernel)
             if (COUNT) rayClock = (unsigned int) __builtin_readcyclecounter();
             if (PRIMARY && entryA.x > 0)
             {
+              sp = 0; // the tile's list was opened from both nodes of the root
               // the tile's entry points instead of the root: the first goes next, the others wait on the stack, nearest on top
               node = entryA.y;
               const int count = entryA.x;
@@ -501,6 +503,7 @@ traceKernel(LaunchParams p, int depth)
           setupRay(ray, org, dir);
           woopSetup(dir, woop);
           currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
+          if (p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; }
           state |= ST_HAS_RAY;
         }
         else if (state & ST_OVERFLOWED) { state &= ~ST_OVERFLOWED; }
@@ -764,6 +767,7 @@ __global__ void __launch_bounds__(64) tileEntryKernel(LaunchParams p, const floa
   bool  closed[TWK_ENTRY_REFS + 4]; // an inner entry whose children did not fit: stays one reference
   int n = 1;
   ref[0] = p.topRoot; key[0] = 0.0f; closed[0] = false;
+  if (p.topRoot2 != TWK_BVH_SENTINEL) { ref[1] = p.topRoot2; key[1] = 0.0f; closed[1] = false; n = 2; } // both nodes of an 8-wide root
   for (int round = 0; round < 64; ++round)
   {
     // the nearest inner entry that still fits when opened
