@@ -12,7 +12,7 @@ import tweeker_raytracer_amd as twk  # noqa: E402
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "scene_rtigo3_cornell_box.txt"
 levels = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-system = open(os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box.txt")).read()
+system = open(os.path.join(ROOT, "scenes", sys.argv[3] if len(sys.argv) > 3 else "system_rtigo3_cornell_box.txt")).read()
 app = twk.Application(system_text=system, scene_text=open(os.path.join(ROOT, "scenes", scene)).read())
 dev = twk.Device(ordinal=0, miss=app.info.miss)
 app.initDevice(dev)
