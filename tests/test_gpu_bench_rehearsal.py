@@ -68,3 +68,33 @@ def test_two_ranks_weak_mode():
     assert res["config"]["composite_bit_identical_to_single_device"] is True
     w, h = res["config"]["resolution"]
     assert abs(w * h - 2 * 1920 * 1080) < 0.01 * 2 * 1920 * 1080 and w % 8 == 0 and h % 8 == 0
+
+
+def test_single_gpu_line_carries_the_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` — the driver's N = 1 command with a short CPU sample: ONE JSON line with
+    the contract's fields, the roofline block of the dominant kernel (algorithmic bytes / measured launch duration / spec
+    peak) and the CPU baseline; value = pixels x steps / the timed region."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in res, key
+    assert res["n_gpus"] == 1 and res["steps"] == 6 and res["warmup"] == 2 and res["unit"] == "Msamples/s" and res["higher_is_better"] is True
+    assert res["dtype"] == "f32" and res["data"] == "synthetic" and res["vs_baseline"] is None and "workload" in res["config"]
+    assert abs(res["value"] - 1920 * 1080 / (res["ms_per_step"] * 1.0e3)) < 1.0e-6 * res["value"]
+    roof = res["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1.0e-9 and roof["achieved"] > 0
+    assert roof["kernel"].startswith("twk::traceKernel<") and roof["avg_launch_ms"] > 0
+    cpu = res["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["sample_bit_identical_to_gpu"] is True
