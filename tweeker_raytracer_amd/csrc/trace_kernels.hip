@@ -72,6 +72,9 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 #ifndef TWK_TRACE_REFILL
 #define TWK_TRACE_REFILL 52
 #endif
+#ifndef TWK_TRACE_REFILL_PRIMARY
+#define TWK_TRACE_REFILL_PRIMARY 32 // the PRIMARY build computes its rays at the refill: fewer, fuller refills (primary launch alone, C2 / C4 geometry: 52: 0.0522 / 0.0896 ms per step, 44: 0.0509 / 0.0891, 32: 0.0512 / 0.0889, 16: 0.0506 / 0.0891, 1: 0.0551 / 0.1012)
+#endif
 // The node loop of a round ends once fewer than NUM/DEN of the lanes that entered it are still at an inner node.
 #ifndef TWK_TRACE_TAIL_DEN
 #define TWK_TRACE_TAIL_DEN 2
@@ -543,7 +546,7 @@ traceKernel(LaunchParams p, int depth)
       if (!(state & ST_HAS_RAY)) node = TWK_BVH_SENTINEL; // what the node loop's condition relies on
       const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
       if (active == 0ull) break;
-      if (!exhausted && __popcll(active) < min(TWK_TRACE_REFILL, (int) ticketSize)) break;
+      if (!exhausted && __popcll(active) < min(PRIMARY ? TWK_TRACE_REFILL_PRIMARY : TWK_TRACE_REFILL, (int) ticketSize)) break;
     }
   }
 
