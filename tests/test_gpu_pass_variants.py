@@ -216,3 +216,41 @@ def test_tile_entry_points_follow_the_camera(twk, monkeypatch):
     for a, b in zip(on, off):
         assert np.array_equal(_bits(a), _bits(b))
     assert not np.array_equal(_bits(on[0]), _bits(on[1]))
+
+
+def test_profiled_kernel_times_do_not_exceed_the_wall_time_of_a_two_lane_pass(twk):
+    """passes of at most TWK_LANES2_MAX_PATHS paths run as two lanes whose launches overlap in time; the
+    per-kind sums of twk_profile_get are sums of launch durations, so with overlapping lanes they came out at about twice
+    the wall time (bench.py feeds them into the roofline). A profiled pass runs as one lane: the sum of all kinds stays
+    within the wall time of the same passes, and the image does not depend on it."""
+    import time
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (960, 540))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    dev.setLaunchBatch(8)           # 4.1 M paths per pass: two lanes by default
+    for it in range(8):
+        dev.render(it)
+    dev.synchronizeStream()
+    plain = dev.getOutputBufferHost().copy()
+    dev.profileEnable(True)
+    dev.profileReset()
+    t0 = time.perf_counter()
+    for it in range(8, 24):
+        dev.render(it)
+    dev.synchronizeStream()
+    wall_ms = (time.perf_counter() - t0) * 1.0e3
+    prof = dev.profileGet()
+    dev.profileEnable(False)
+    total = sum(v["ms"] for v in prof.values())
+    assert prof["trace"]["launches"] == 2 * 11 and prof["shade"]["launches"] == 2 * 10, "one lane: one launch per kind and depth and pass"
+    assert 0.0 < total <= wall_ms, f"kernel times {total:.3f} ms of two passes exceed their wall time {wall_ms:.3f} ms"
+    # the same 24 iterations without the profile (two lanes): the same image
+    other = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(other)
+    other.setLaunchBatch(8)
+    for it in range(24):
+        other.render(it)
+    assert np.array_equal(_bits(other.getOutputBufferHost()), _bits(dev.getOutputBufferHost()))
+    assert not np.array_equal(_bits(plain), _bits(dev.getOutputBufferHost()))
+    other.close()
+    dev.close()

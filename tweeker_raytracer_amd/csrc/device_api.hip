@@ -75,6 +75,15 @@ struct InstanceHost
 };
 
 struct TimedLaunch { hipEvent_t start, stop; int kind; };
+// What a table of primary-ray entry points (trace_kernels.hip tileEntryKernel) was built for: camera bits, frame, tree, tile
+// distribution. Compared with memcmp (as floats, TWK_NODE_CACHED | 1 rounded to TWK_NODE_CACHED | 0, a build serial
+// stopped counting at 2^24, and -0.0 compared equal to +0.0).
+struct TileEntriesKey
+{
+  uint32_t camera[12];
+  int32_t  resolution[2], topRoot, topRoot2, launchWidth, deviceCount, deviceIndex, tileSize[2], valid;
+  uint64_t buildSerial;
+};
 #define TWK_MAX_LANES 4
 #define TWK_COUNTER_WORDS (TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)) // one lane's counter block
 
@@ -106,7 +115,7 @@ struct TwkDevice_t
   float* d_attributes = nullptr; unsigned int* d_indices = nullptr;
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
   bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ bool tileEntries = true; /* TWK_TILE_ENTRIES=0: A/B */ bool wideRoot = true; /* TWK_WIDE_ROOT=0: A/B */ int wideRoot1 = 0, wideRoot2 = TWK_BVH_SENTINEL; size_t wideNodesTotal = 0;
-  int4* d_tileEntries = nullptr; size_t tileEntriesCapacity = 0; std::vector<float> tileEntriesKey; unsigned int buildSerial = 0; // entry points of the primary rays (trace_kernels.hip tileEntryKernel) and what they were built for
+  int4* d_tileEntries = nullptr; size_t tileEntriesCapacity = 0; TileEntriesKey tileEntriesKey = {}; uint64_t buildSerial = 0; // entry points of the primary rays (trace_kernels.hip tileEntryKernel) and what they were built for
   float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
@@ -270,7 +279,8 @@ static void refreshParams(TwkDevice dev)
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   p.outputFrame = (dev->d_outputExternal && dev->outputFrame) ? 1 : 0;
   p.counters = dev->d_counters;
-  p.stats = (dev->statsEnabled || dev->timeView) ? dev->d_stats : nullptr; // the time view runs the measurement builds of the kernels, which tally
+  // the time view runs the measurement builds of the kernels, which tally: into a scratch block unless statistics are on
+  p.stats = dev->statsEnabled ? dev->d_stats : (dev->timeView ? dev->d_stats + 24 : nullptr);
   p.pathTime = dev->timeView ? dev->d_pathTime : nullptr; p.clockScale = dev->state.clockFactor * 1.0e-9f; // Device.h:350 CLOCK_FACTOR_SCALE
   p.shaderVariant = dev->shaderVariant;
   p.pathAlbedo = dev->aovEnabled ? dev->d_pathAlbedo : nullptr; p.pathNormal = dev->aovEnabled ? dev->d_pathNormal : nullptr;
@@ -343,14 +353,16 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     }
   }
   if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTER_WORDS * TWK_MAX_LANES));
-  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 24)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 24, dev->stream)); }
+  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 48)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 48, dev->stream)); } // TwkLaunchStats words + a scratch block for the time view
   if (!dev->h_dropped)
   {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->h_dropped), sizeof(unsigned int), hipHostMallocMapped));
     *dev->h_dropped = 0u;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev->d_dropped), dev->h_dropped, 0));
   }
-  const size_t lanes = (size_t) 2 * traceGridBlocks(dev) * TWK_TRACE_BLOCK; // two full grids: the lanes of a pass may each be given more than their share of a grid (TWK_LANE_TRACE_WAVES)
+  // one full grid of per-lane spill stacks (the lanes of a pass share it); two only under the experiments-only
+  // TWK_LANE_TRACE_WAVES knob, which may give every lane more than its share of a grid (264 MB per handle otherwise)
+  const size_t lanes = (size_t) (dev->laneTraceWaves > 0 ? 2 : 1) * traceGridBlocks(dev) * TWK_TRACE_BLOCK;
   if (lanes > dev->spillLanes)
   {
     freeDevice(dev->d_spill);
@@ -521,6 +533,9 @@ static int chooseLanes(TwkDevice dev, int numPaths)
   if (dev->lanesForced > 0) lanes = dev->lanesForced;
   else if (numPaths <= TWK_LANES2_MAX_PATHS) lanes = 2;
   if (dev->captureFirstHits || dev->tailDepth > 0) lanes = 1; // debug capture indexes by launch index; the tail kernel owns the whole grid
+  // twk_profile_enable: the per-kind sums of twk_profile_get are sums of launch durations; the launches of two lanes overlap
+  // in time, so their sum would be about twice the wall time of the kind. A profiled pass runs as ONE lane.
+  if (dev->profileEnabled) lanes = 1;
   while (lanes > 1 && numPaths / lanes < 4096) --lanes;
   return std::min(lanes, TWK_MAX_LANES);
 }
@@ -585,16 +600,19 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   {
     const int tilesX = (p.launchWidth + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE, tilesY = (p.resolution[1] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE;
     const size_t need = (size_t) tilesX * tilesY * 2;
-    std::vector<float> key(reinterpret_cast<const float*>(&dev->cameras[0]), reinterpret_cast<const float*>(&dev->cameras[0]) + 12);
-    key.push_back((float) p.resolution[0]); key.push_back((float) p.resolution[1]); key.push_back((float) dev->buildSerial); key.push_back((float) p.topRoot); key.push_back((float) p.topRoot2);
-    key.push_back((float) p.launchWidth); key.push_back((float) (distributed ? p.deviceCount : 1)); key.push_back((float) p.deviceIndex); key.push_back((float) p.tileSize[0]); key.push_back((float) p.tileSize[1]);
+    TileEntriesKey key;
+    memset(&key, 0, sizeof(key)); // padding bytes too: the keys are compared with memcmp
+    memcpy(key.camera, &dev->cameras[0], sizeof(key.camera));
+    key.resolution[0] = p.resolution[0]; key.resolution[1] = p.resolution[1]; key.topRoot = p.topRoot; key.topRoot2 = p.topRoot2;
+    key.launchWidth = p.launchWidth; key.deviceCount = distributed ? p.deviceCount : 1; key.deviceIndex = p.deviceIndex;
+    key.tileSize[0] = p.tileSize[0]; key.tileSize[1] = p.tileSize[1]; key.valid = 1; key.buildSerial = dev->buildSerial;
     if (need > dev->tileEntriesCapacity)
     {
-      freeDevice(dev->d_tileEntries); dev->tileEntriesCapacity = 0; dev->tileEntriesKey.clear();
+      freeDevice(dev->d_tileEntries); dev->tileEntriesCapacity = 0; memset(&dev->tileEntriesKey, 0, sizeof(dev->tileEntriesKey));
       HIP_TRY(hipMalloc(&dev->d_tileEntries, sizeof(int4) * need));
       dev->tileEntriesCapacity = need;
     }
-    if (key != dev->tileEntriesKey)
+    if (memcmp(&key, &dev->tileEntriesKey, sizeof(key)) != 0)
     {
       // the table the PRIMARY build of the traversal kernel caches: TWK_PRIMARY_SIX -> the six-block build's
       const float4* topTable = (TWK_PRIMARY_SIX || p.traceWaves != TWK_TRACE_WAVES7) ? p.topNodes : p.topNodes7;
@@ -1600,7 +1618,7 @@ try
   HIP_TRY(hipMemcpyAsync(tBetaGamma, d_out.ptr, numRays * 3 * sizeof(float), hipMemcpyDeviceToHost, dev->stream));
   HIP_TRY(hipMemcpyAsync(ids, d_ids.ptr, numRays * 2 * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  return TWK_SUCCESS;
+  return checkDroppedPushes(dev, "twk_trace_rays");
 }
 TWK_CATCH("twk_trace_rays")
 
@@ -1621,7 +1639,8 @@ try
   if ((size_t) dev->allocatedPaths < n) return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "twk_debug_trace_queue: path streams too small");
   refreshParams(dev);
   LaunchParams p = dev->params;
-  p.numPaths = dev->allocatedPaths; p.batchCount = 1; p.firstHit = nullptr; p.firstHitInstance = nullptr; p.stats = nullptr;
+  p.numPaths = dev->allocatedPaths; p.batchCount = 1; p.firstHit = nullptr; p.firstHitInstance = nullptr; p.pathTime = nullptr;
+  p.stats = dev->statsEnabled ? dev->d_stats : nullptr; // twk_stats_enable: visit counts and the number of rays that overflowed the LDS stack (tests/test_gpu_big_scenes.py)
   // the rays of one bounce: radiance rays in queue 1, the shadow rays "emitted by shade 0" in the shadow queue
   std::vector<float4> org(n), dir(n);
   std::vector<unsigned int> index(n);
@@ -1657,9 +1676,10 @@ try
     const unsigned int c = (unsigned int) numShadow;
     HIP_TRY(hipMemcpy(dev->d_counters + 0 * TWK_COUNTERS_PER_DEPTH + 1, &c, sizeof(c), hipMemcpyHostToDevice));
   }
-  launchTrace(p, 1, false, false, dev->numCUs * p.traceWaves, dev->stream);
+  launchTrace(p, 1, dev->statsEnabled, false, dev->numCUs * p.traceWaves, dev->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(dev->stream));
+  if ((rc = checkDroppedPushes(dev, "twk_debug_trace_queue"))) return rc;
   if (numClosest)
   {
     HIP_TRY(hipMemcpy(tBetaGammaSlot, p.hitRecord, numClosest * sizeof(float4), hipMemcpyDeviceToHost));

@@ -605,6 +605,7 @@ traceOverflowKernel(LaunchParams p, int depth)
       d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
     }
     float tmin = (PRIMARY && CUTOUT) ? p.hitRecord[slot].x : o.w; // carries the distance of the last ignored cutout candidate, if any
+    const unsigned int rayClock = COUNT ? (unsigned int) __builtin_readcyclecounter() : 0u; // time view: this lane's cycles for the re-trace
     TraceResult res;
     for (;;)
     {
@@ -612,6 +613,8 @@ traceOverflowKernel(LaunchParams p, int depth)
       if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY))) break;
       tmin = res.t;
     }
+    if (COUNT && p.pathTime != nullptr)
+      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[slot - numClosest] : (PRIMARY ? slot : p.rayPixel[q][slot])], float((unsigned int) __builtin_readcyclecounter() - rayClock));
     if (!isShadow)
     {
       p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
