@@ -27,7 +27,9 @@ extern "C" {
 
 /* 3: TwkLaunchStats grew by waveCycles[6] (twk_stats_get writes sizeof(TwkLaunchStats) bytes) and
  * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
-#define TWK_ABI_VERSION 7
+/* 8: TwkBuildInfo grew by wide8Nodes / wide8Levels; TwkAccelerationInfo.reserved became nodeFloats — twk_debug_read_acceleration
+ * hands out the compressed 8-ary nodes (20 floats each) where the persistent kernel walks those. */
+#define TWK_ABI_VERSION 8
 
 typedef enum TwkResult
 {
@@ -230,6 +232,8 @@ typedef struct TwkBuildInfo
   uint64_t maxTraversalDepth; /* ABI 4: binary-tree levels of the deepest root-to-leaf path (top level + the deepest tree below it); twk_build refuses a scene deeper than the traversal stacks */
   uint64_t directLeafInstances; /* ABI 5: flattened instances of at most a leaf's triangles that ARE leaves of the top level (no tree of their own is visited) */
   uint64_t traceBlocksPerCU;    /* ABI 5: resident blocks per CU of the persistent traversal kernel for this scene with the materials as they are now: 6, or 7 (flattened, no cutout opacity, at most 1 M nodes) */
+  uint64_t wide8Nodes;          /* ABI 8: compressed 8-ary nodes the persistent kernel walks instead of the 4-ary ones (csrc/bvh_wide8.hip; flattened scenes), 0: none were built */
+  uint64_t wide8Levels;         /* ABI 8: depth of that 8-ary tree */
 } TwkBuildInfo;
 int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info);
 
@@ -364,7 +368,7 @@ typedef struct TwkAccelerationInfo
   int      twoLevel;  /* 0: every instance is flattened, no instance reference occurs */
   uint64_t numNodes, numTriangleSlots, numInstances;
   int      root2;     /* ABI 7: the second wide node of an 8-wide root (a ray starts at `root` with `root2` on its stack), -1: none */
-  int      reserved;
+  int      nodeFloats; /* ABI 8: floats per node record: 16 = quantised 4-ary node (64 B), 20 = compressed 8-ary node (80 B, root = node 0, csrc/device_types.h) */
 } TwkAccelerationInfo;
 int twk_debug_read_acceleration(TwkDevice dev, TwkAccelerationInfo* info, void* wideNodes, void* triangles, void* instances);
 

@@ -75,14 +75,15 @@ class LaunchStats(C.Structure):
 
 class AccelerationInfo(C.Structure):
     _fields_ = [("root", C.c_int), ("twoLevel", C.c_int), ("numNodes", C.c_uint64), ("numTriangleSlots", C.c_uint64), ("numInstances", C.c_uint64),
-                ("root2", C.c_int), ("reserved", C.c_int)]
+                ("root2", C.c_int), ("nodeFloats", C.c_int)]
 
 
 class BuildInfo(C.Structure):
     _fields_ = [("quality", C.c_int), ("trees", C.c_int), ("sahInnerCost", C.c_double), ("sahLeafCost", C.c_double),
                 ("buildMilliseconds", C.c_double), ("triangleSlots", C.c_uint64), ("nodes", C.c_uint64),
                 ("instances", C.c_uint64), ("flattenedInstances", C.c_uint64), ("maxTraversalDepth", C.c_uint64),
-                ("directLeafInstances", C.c_uint64), ("traceBlocksPerCU", C.c_uint64)]
+                ("directLeafInstances", C.c_uint64), ("traceBlocksPerCU", C.c_uint64),
+                ("wide8Nodes", C.c_uint64), ("wide8Levels", C.c_uint64)]
 
 
 class AppInfo(C.Structure):

@@ -249,7 +249,7 @@ class Device:
         """(info dict, quantised wide nodes float32 [n, 16], triangle slots float32 [m, 12], instance records float32 [k, 32]) of the built scene."""
         info = L.AccelerationInfo()
         L.check(L.lib.twk_debug_read_acceleration(self._h, C.byref(info), None, None, None))
-        nodes = np.zeros((info.numNodes, 16), np.float32)  # quantised wide nodes, 64 B
+        nodes = np.zeros((info.numNodes, info.nodeFloats), np.float32)  # quantised 4-ary nodes (64 B) or compressed 8-ary nodes (80 B): info.nodeFloats
         tris = np.zeros((info.numTriangleSlots, 12), np.float32)
         inst = np.zeros((info.numInstances, 32), np.float32)
         L.check(L.lib.twk_debug_read_acceleration(self._h, C.byref(info), nodes.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p),
