@@ -183,7 +183,8 @@ def test_big_room_windows_path_rays_and_overflow_against_the_oracle(twk, orc, mo
     dev.statsEnable(False)
     print(f"tess {tess}, {blocks} blocks per CU, wide8 {wide8} ({info['wide8Nodes']} nodes, {info['wide8Levels']} levels): frame overflow rays {frame_stats['overflowRays']} of {frame_stats['radianceRays'] + frame_stats['shadowRays']}, "
           f"query overflow rays {query_stats['overflowRays']} of {closest.shape[0] + shadow.shape[0]}, deepest ray {query_stats['maxNodesPerRay']} node steps, dropped pushes {query_stats['droppedStackPushes']}")
-    assert query_stats["overflowRays"] > 0, "the pole rays are built to outgrow the LDS stack: the HBM-continued traversal is what is checked here"
+    if wide8 == "0":  # (the 8-ary nodes keep ONE stack entry per level: these rays stay within the LDS stack there)
+        assert query_stats["overflowRays"] > 0, "the pole rays are built to outgrow the LDS stack: the HBM-continued traversal is what is checked here"
     assert query_stats["droppedStackPushes"] == 0 and frame_stats["droppedStackPushes"] == 0
     _, _, tris, _ = dev.readAcceleration()
     slot_primitive = tris[:, 3].view(np.int32)
