@@ -243,6 +243,9 @@ struct LaunchParams
   // TWK_ENTRY_TILE launch indices two int4 = (count, ref 0..6): the subtrees a ray through that tile can reach, nearest first.
   const int4* tileEntries;
   int     tilesX;
+  // Experiment builds only (-DTWK_EXPERIMENT_PRESETUP=1, tools/experiments/): two float4 per queue slot of the traversal launch —
+  // (1 / d guarded, Woop permutation bits) and (Sx, Sy, Sz, 0) — written by raySetupKernel in front of it; nullptr otherwise.
+  float4* raySetup;
   unsigned int* droppedPushes; // pinned host word (device-mapped): pushes the single-ray traversal could not store (trace_device.h TWK_PUSH); stays 0 on every scene twk_build accepts
 };
 

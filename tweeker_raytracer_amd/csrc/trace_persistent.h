@@ -252,8 +252,22 @@ traceKernel(LaunchParams p, int depth)
             else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT); }
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
+#if TWK_EXPERIMENT_PRESETUP
+            // experiment: what the refill computes per ray — three guarded reciprocals, the Woop
+            // permutation and its three IEEE divisions — comes from a stream a full-occupancy kernel wrote in front of this launch
+            if (!PRIMARY && p.raySetup != nullptr)
+            {
+              const float4 sa = p.raySetup[2 * (size_t) slot], sb = p.raySetup[2 * (size_t) slot + 1];
+              ray.o = org; ray.d = dir; ray.id = v3(sa.x, sa.y, sa.z);
+              ray.ood = v3(org.x * ray.id.x, org.y * ray.id.y, org.z * ray.id.z);
+              woop.perm = __float_as_uint(sa.w); woop.Sx = sb.x; woop.Sy = sb.y; woop.Sz = sb.z;
+            }
+            else
+#endif
+            {
             setupRay(ray, org, dir);
             woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
+            }
             currentInstance = -1; sp = 0; guard = 0;
             if (WIDE8)
             {
