@@ -138,6 +138,7 @@ struct TwkDevice_t
   unsigned int* h_dropped = nullptr; unsigned int* d_dropped = nullptr; // pinned + device-mapped: LaunchParams::droppedPushes
   int* d_spill = nullptr; size_t spillLanes = 0;
   float4* d_raySetup = nullptr; size_t raySetupPaths = 0; // experiment builds only (TWK_EXPERIMENT_PRESETUP)
+  bool packedQueue = true; // TWK_PACKED_QUEUE=0: A/B
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
   // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
   bool aovEnabled = false; int shaderVariant = TWK_SHADERS_RTIGO3;
@@ -296,6 +297,7 @@ static void refreshParams(TwkDevice dev)
   p.firstHitInstance = dev->captureFirstHits ? dev->d_firstHitInstance : nullptr;
   p.traceStackSpill = dev->d_spill;
   p.droppedPushes = dev->d_dropped;
+  p.packedQueue = 0; // renderPass decides per pass
   p.raySetup = nullptr;
 #if TWK_EXPERIMENT_PRESETUP
   p.raySetup = dev->d_raySetup;
@@ -595,6 +597,8 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   p.numPaths = p.numPixels * p.batchCount;
   p.pathBase = 0;
 
+  // launch index + path flags and the LCG state in the constant words of the queued rays (device_types.h LaunchParams::packedQueue)
+  p.packedQueue = (dev->packedQueue && !p.hasCutout && dev->tailDepth == 0 && (unsigned int) p.numPaths <= TWK_PACKED_PIXEL_MASK) ? 1 : 0;
   const int maxDepth = dev->state.pathLengths[1];
   const int lanes = chooseLanes(dev, p.numPaths);
   // every block of every lane's persistent trace kernel resident at once: the lanes share the CUs' block slots
@@ -773,6 +777,7 @@ try
   if (const char* e = getenv("TWK_TILE_ENTRIES")) dev->tileEntries = (atoi(e) != 0);
   if (const char* e = getenv("TWK_WIDE_ROOT")) dev->wideRoot = (atoi(e) != 0);
   if (const char* e = getenv("TWK_WIDE8")) dev->wide8Mode = (atoi(e) != 0) ? 1 : 0;
+  if (const char* e = getenv("TWK_PACKED_QUEUE")) dev->packedQueue = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));

@@ -42,6 +42,10 @@ static const float DENOMINATOR_EPSILON = 1.0e-6f;
 // survives FLAG_CLEAR_MASK, raygeneration.cu:66), bits 8-15 depth, bits 16-18 volume stack index + 1.
 #define TWK_PATH_DEPTH_SHIFT 8
 #define TWK_PATH_STACK_SHIFT 16
+// Packed queue records (LaunchParams::packedQueue): origin.w = launch index (27 bits) | FLAG_DIFFUSE << 27 | FLAG_ALBEDO << 28 |
+// (volume stack index + 1) << 29; direction.w = the LCG state.
+#define TWK_PACKED_PIXEL_BITS 27
+#define TWK_PACKED_PIXEL_MASK ((1u << TWK_PACKED_PIXEL_BITS) - 1u)
 
 // ≙ MaterialDefinition (shaders/material_definition.h:37-56), 64 B
 struct DevMaterial
@@ -246,6 +250,11 @@ struct LaunchParams
   // Experiment builds only (-DTWK_EXPERIMENT_PRESETUP=1, tools/experiments/): two float4 per queue slot of the traversal launch —
   // (1 / d guarded, Woop permutation bits) and (Sx, Sy, Sz, 0) — written by raySetupKernel in front of it; nullptr otherwise.
   float4* raySetup;
+  // 1: the queues shadeKernel writes (every depth >= 1) carry launch index + path flags in the .w of the origin and the LCG state in
+  // the .w of the direction — the tmin / tmax of a continuation ray are the constants sceneEpsilon / RT_DEFAULT_MAX — and the
+  // rayPixel / raySeedFlags streams are neither written nor read: 12 bytes less per path and bounce on both sides (TWK_PACKED_*).
+  // Scenes without cutout opacity (its candidate loop keeps a per-ray tmin in the record), passes of fewer than 2^27 paths.
+  int     packedQueue;
   unsigned int* droppedPushes; // pinned host word (device-mapped): pushes the single-ray traversal could not store (trace_device.h TWK_PUSH); stays 0 on every scene twk_build accepts
 };
 

@@ -130,6 +130,7 @@ traceKernel(LaunchParams p, int depth)
   const unsigned int total = numClosest + numShadow;
 
   const int q = depth & 1;
+  const bool packed = !CUTOUT && !PRIMARY && p.packedQueue != 0 && depth > 0; // device_types.h LaunchParams::packedQueue: the closest-hit rays' .w words are not tmin / tmax
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
@@ -248,7 +249,11 @@ traceKernel(LaunchParams p, int depth)
                 entryA = tile[0]; entryB = tile[1];
               }
             }
-            else if (slot < numClosest) { o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; state = ST_HAS_RAY; }
+            else if (slot < numClosest)
+            {
+              o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; state = ST_HAS_RAY;
+              if (packed) { o.w = p.sceneEpsilon; d.w = RT_DEFAULT_MAX; }
+            }
             else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT); }
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
@@ -630,7 +635,7 @@ traceKernel(LaunchParams p, int depth)
           p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
           p.hitInstance[slot] = res.instance;
           if (COUNT) ++closestCount;
-          if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : p.rayPixel[q][slot]], float((unsigned int) __builtin_readcyclecounter() - rayClock)); // time view: the lane's cycles from taking the ray to its result
+          if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : (packed ? (__float_as_uint(p.rayOrg[q][slot].w) & TWK_PACKED_PIXEL_MASK) : p.rayPixel[q][slot])], float((unsigned int) __builtin_readcyclecounter() - rayClock)); // time view: the lane's cycles from taking the ray to its result
           if (p.firstHit != nullptr && depth == 0)
           {
             const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
@@ -700,6 +705,7 @@ traceOverflowKernel(LaunchParams p, int depth)
   int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
   const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
   const int q = depth & 1;
+  const bool packed = !CUTOUT && !PRIMARY && p.packedQueue != 0 && depth > 0; // as in traceKernel
   unsigned int nodeCount = 0, triCount = 0, instCount = 0;
   for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
   {
@@ -717,6 +723,8 @@ traceOverflowKernel(LaunchParams p, int depth)
       o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
       d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
     }
+    const unsigned int packedPixel = __float_as_uint(o.w) & TWK_PACKED_PIXEL_MASK;
+    if (packed && !isShadow) { o.w = p.sceneEpsilon; d.w = RT_DEFAULT_MAX; }
     float tmin = (PRIMARY && CUTOUT) ? p.hitRecord[slot].x : o.w; // carries the distance of the last ignored cutout candidate, if any
     const unsigned int rayClock = COUNT ? (unsigned int) __builtin_readcyclecounter() : 0u; // time view: this lane's cycles for the re-trace
     TraceResult res;
@@ -727,7 +735,7 @@ traceOverflowKernel(LaunchParams p, int depth)
       tmin = res.t;
     }
     if (COUNT && p.pathTime != nullptr)
-      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[slot - numClosest] : (PRIMARY ? slot : p.rayPixel[q][slot])], float((unsigned int) __builtin_readcyclecounter() - rayClock));
+      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[slot - numClosest] : (PRIMARY ? slot : (packed ? packedPixel : p.rayPixel[q][slot]))], float((unsigned int) __builtin_readcyclecounter() - rayClock));
     if (!isShadow)
     {
       p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
