@@ -265,7 +265,7 @@ static void refreshParams(TwkDevice dev)
   p.hasCutout = 0; p.hasAlbedoTexture = 0;
   for (const DevMaterial& m : dev->materials) { if (m.textureCutout != 0) p.hasCutout = 1; if (m.textureAlbedo != 0) p.hasAlbedoTexture = 1; }
   // seven trace blocks per CU where the variant that fits them applies (device_types.h TWK_TRACE_WAVES7)
-  p.traceWaves = (!dev->twoLevel && !p.hasCutout && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : (p.hasCutout ? TWK_TRACE_WAVES_CUTOUT : TWK_TRACE_WAVES);
+  p.traceWaves = (!dev->twoLevel && !p.hasCutout && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : (p.hasCutout ? (dev->twoLevel ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES_CUTOUT) : TWK_TRACE_WAVES);
   if (dev->traceWavesForced == TWK_TRACE_WAVES || (dev->traceWavesForced == TWK_TRACE_WAVES7 && !dev->twoLevel && !p.hasCutout)) p.traceWaves = dev->traceWavesForced;
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)
@@ -688,7 +688,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   {
     const bool primary = fusedPrimary && depth == 0;
     // (the PRIMARY build of the traversal kernel needs more registers than seven blocks per CU leave: six at most)
-    const int primaryWaves = p.hasCutout ? TWK_TRACE_WAVES_CUTOUT : (p.twoLevel ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : TWK_TRACE_WAVES_PRIMARY);
+    const int primaryWaves = p.hasCutout ? TWK_TRACE_WAVES_CUTOUT_OTHER : (p.twoLevel ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : TWK_TRACE_WAVES_PRIMARY);
     const int grid = (primary && TWK_PRIMARY_SIX) ? std::min(traceGrid, dev->numCUs * std::max(1, primaryWaves / lanes)) : traceGrid;
     for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], depth, dev->statsEnabled || dev->timeView, primary, grid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
     for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_SHADE, laneS[k]); launchShade(laneP[k], depth, primary, shadeGrid[k], laneS[k]); timedLaunchEnd(dev, laneS[k]); }

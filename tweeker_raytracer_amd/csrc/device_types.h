@@ -281,7 +281,10 @@ struct LaunchParams
 // need 76..91 VGPRs and spill at 72 (C4 instances -11 %, C3 -16 %), and scenes of millions of triangles lose 2-6 % (the
 // smaller cache and stack matter there), so those keep six blocks, a 20-entry stack and 64 cached nodes.
 #ifndef TWK_TRACE_WAVES_CUTOUT
-#define TWK_TRACE_WAVES_CUTOUT 5 // blocks per CU of the builds with cutout opacity: they need 93-95 VGPRs; at six blocks (80) 17-27 were spilled — C3 trace 0.277 -> 0.230 ms/step at five
+#define TWK_TRACE_WAVES_CUTOUT 6 // blocks per CU of the flattened build with cutout opacity (round 4: 79 VGPRs since a ray whose candidate is ignored is handed to traceOverflowKernel instead of restarting in place; rounds 2-3: 93-95 VGPRs, five blocks)
+#endif
+#ifndef TWK_TRACE_WAVES_CUTOUT_OTHER
+#define TWK_TRACE_WAVES_CUTOUT_OTHER 5 // ... of its PRIMARY and two-level builds (93-94 VGPRs; at six 36-100 bytes of scratch)
 #endif
 #ifndef TWK_TRACE_WAVES_PRIMARY
 #define TWK_TRACE_WAVES_PRIMARY TWK_TRACE_WAVES // blocks per CU of the PRIMARY builds (flattened: 80 VGPRs, 2 spilled at six)

@@ -99,7 +99,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // (childBase, hit mask) stack entry per node, children in octant order, the triangles of a node's leaf children tested
 // before its inner children are entered.
 template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY, bool WIDE8>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : (CUTOUT ? TWK_TRACE_WAVES_CUTOUT : ((PRIMARY && TWO_LEVEL) ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : (PRIMARY ? TWK_TRACE_WAVES_PRIMARY : TWK_TRACE_WAVES)))) // blocks per CU = waves per SIMD: device_types.h
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : (CUTOUT ? ((PRIMARY || TWO_LEVEL) ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES_CUTOUT) : ((PRIMARY && TWO_LEVEL) ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : (PRIMARY ? TWK_TRACE_WAVES_PRIMARY : TWK_TRACE_WAVES)))) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
   static_assert(!(WIDE8 && TWO_LEVEL), "the 8-ary nodes are built for flattened scenes");
@@ -619,10 +619,24 @@ traceKernel(LaunchParams p, int depth)
                                       cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY);
         if (ignoredCandidate)
         {
-          // continue strictly behind the ignored candidate: restart the traversal with tmin = its distance
+          // continue strictly behind the ignored candidate: the traversal starts again with tmin = its distance. The ray comes from
+          // its record again (PRIMARY: is computed again) — kept in registers for this, origin and direction cost the cutout builds
+          // 14 VGPRs and their sixth block per CU (rounds 2-3: 93-95 VGPRs, five blocks; round 4: 79, six).
           tmin = res.t;
-          res.t = isShadow ? p.shadowDir[slot - numClosest].w : (PRIMARY ? RT_DEFAULT_MAX : p.rayDir[q][slot].w);
-          res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
+          float4 o, d;
+          if (PRIMARY)
+          {
+            const PrimaryRay pr = primaryRay(p, slot);
+            o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, 0.0f);
+            d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, RT_DEFAULT_MAX);
+          }
+          else
+          {
+            o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
+            d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+          }
+          org = v3(o); dir = v3(d);
+          res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
           setupRay(ray, org, dir);
           woopSetup(dir, woop);
           currentInstance = -1; sp = 0; node = WIDE8 ? 0 : p.topRoot; guard = 0;
