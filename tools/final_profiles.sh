@@ -9,10 +9,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 # PMC passes first: the bench lines below then carry the traffic of THESE kernels
 bash tools/pmc_collect.sh $TAG/pmc_s20 20 5 > $OUT/pmc_s20.log 2>&1
-python3 tools/pmc_traffic.py $OUT/pmc_s20 profiles/r03_trace_hbm_traffic_s20.json > /dev/null && cp profiles/r03_trace_hbm_traffic_s20.json $OUT/
+python3 tools/pmc_traffic.py $OUT/pmc_s20 profiles/r04_trace_hbm_traffic_s20.json > /dev/null && cp profiles/r04_trace_hbm_traffic_s20.json $OUT/
 python3 tools/pmc_summarize.py $OUT/pmc_s20 $OUT/pmc_summary_s20.md > /dev/null
 bash tools/pmc_collect.sh $TAG/pmc_s64 64 64 > $OUT/pmc_s64.log 2>&1
-python3 tools/pmc_traffic.py $OUT/pmc_s64 profiles/r03_trace_hbm_traffic_s64.json > /dev/null && cp profiles/r03_trace_hbm_traffic_s64.json $OUT/
+python3 tools/pmc_traffic.py $OUT/pmc_s64 profiles/r04_trace_hbm_traffic_s64.json > /dev/null && cp profiles/r04_trace_hbm_traffic_s64.json $OUT/
 python3 tools/pmc_summarize.py $OUT/pmc_s64 $OUT/pmc_summary_s64.md > /dev/null
 echo "pmc done"
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_s20.json 2> $OUT/bench_s20.err; echo "bench s20 rc $?"
