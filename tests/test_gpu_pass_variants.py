@@ -87,7 +87,7 @@ def test_wide_root_is_built_where_it_pays(twk, monkeypatch):
 
 def test_build_info_names_the_direct_leaves_and_the_kernel_build(twk):
     """Cornell box: five walls + the area light are two-triangle instances, all flattened -> the seven-block build;
-    the instances scene enters instances -> six blocks; intro_07 has cutout opacity -> six blocks."""
+    the instances scene enters instances -> six blocks (intro_07, flattened with cutout opacity: seven since round 4)."""
     for system, scene, leaves, blocks in [("system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", 6, 7),
                                           ("system_rtigo3_instances.txt", "scene_rtigo3_instances.txt", 1, 6)]:
         app = load_app(twk, system, scene, (32, 32))

@@ -83,6 +83,7 @@ void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int
     return;
   }
   if (p.twoLevel) { if (count) launchTraceVariant<true, true, true,  false, false>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, true,  false, false>(p, depth, gridBlocks, stream); }
+  else if (p.traceWaves == TWK_TRACE_WAVES7) { if (count) launchTraceVariant<true, true, false, true, false>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, false, true, false>(p, depth, gridBlocks, stream); } // the flattened cutout build fits seven blocks since round 4 (71 VGPRs)
   else            { if (count) launchTraceVariant<true, true, false, false, false>(p, depth, gridBlocks, stream); else launchTraceVariant<false, true, false, false, false>(p, depth, gridBlocks, stream); }
 }
 

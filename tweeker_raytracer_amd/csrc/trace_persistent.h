@@ -102,7 +102,7 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // (childBase, hit mask) stack entry per node, children in octant order, the triangles of a node's leaf children tested
 // before its inner children are entered.
 template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY, bool WIDE8>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : (CUTOUT ? ((PRIMARY || TWO_LEVEL) ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES_CUTOUT) : ((PRIMARY && TWO_LEVEL) ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : (PRIMARY ? TWK_TRACE_WAVES_PRIMARY : TWK_TRACE_WAVES)))) // blocks per CU = waves per SIMD: device_types.h
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : (CUTOUT ? ((PRIMARY || TWO_LEVEL) ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES) : ((PRIMARY && TWO_LEVEL) ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : (PRIMARY ? TWK_TRACE_WAVES_PRIMARY : TWK_TRACE_WAVES)))) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
   static_assert(!(WIDE8 && TWO_LEVEL), "the 8-ary nodes are built for flattened scenes");
