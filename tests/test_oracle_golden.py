@@ -161,3 +161,42 @@ def test_threaded_render_is_the_same_render(twk, orc):
         out.append((ref.getOutputBufferHost(), ref.counters()))
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
     assert out[0][1] == out[1][1] and out[0][1]["samples"] == 2 * 96 * 54
+
+
+def test_device_built_8ary_tree_fixture_walked_on_the_cpu(twk, orc):
+    """tests/golden/wide8_small_room.npz (made on the GPU box by tests/golden/make_wide8_fixture.py): the compressed 8-ary nodes and
+    triangle slots twk_build produced for a small Cornell room, 4 096 rays, and the persistent kernel's hit records and visit counts
+    for them. Here, without a GPU: the host walker (oracle/same_bvh_walk.cpp orc_walk_same_bvh8) walks that tree — the same hit
+    records bit for bit, the same visit counts (up to the reciprocal of the culling test: v_rcp_f32 there, 1 / d here) — and the
+    oracle's brute force over the same scene, rebuilt here from its description, gives the same hits: the node format, the octant
+    order and the leaf numbering of csrc/bvh_wide8.hip are pinned on the CPU side too."""
+    import importlib.util
+    fx = np.load(os.path.join(GOLDEN, "wide8_small_room.npz"))
+    nodes, tris, rays = fx["nodes"], fx["triangles"], fx["rays"]
+    assert nodes.shape[1] == 20 and tris.shape[1] == 12
+    acc = ({"root": 0, "root2": -1, "nodeFloats": 20}, nodes, tris, np.zeros((1, 32), np.float32))
+    tbg, ids, counts = orc.walk_same_bvh(acc, rays)
+    assert np.array_equal(ids[:, 0], fx["device_instance"]) and np.array_equal(ids[:, 1], fx["device_primitive"])
+    hit = ids[:, 0] >= 0
+    assert 0.7 < hit.mean() < 1.0
+    assert np.array_equal(_bits(tbg[hit]), _bits(fx["device_tbg"][hit]))
+    assert abs(int(counts["nodesVisited"]) - int(fx["device_nodes_visited"])) <= 4 and abs(int(counts["trianglesTested"]) - int(fx["device_triangles_tested"])) <= 4, counts
+    # any-hit walk: occlusion of the same rays cut short
+    shadow = rays.copy()
+    shadow[:, 7] = np.random.default_rng(3).uniform(0.1, 3.0, rays.shape[0]).astype(np.float32)
+    _, occ, _ = orc.walk_same_bvh(acc, shadow, anyHit=True)
+    # the scene the fixture was built from, from its description, through the oracle's brute force
+    spec = importlib.util.spec_from_file_location("make_wide8_fixture", os.path.join(GOLDEN, "make_wide8_fixture.py"))
+    # (the generator module imports the product library, which loads without a GPU; only its scene text and rays are used here)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert np.array_equal(_bits(gen.fixture_rays()), _bits(rays))
+    app = twk.Application(system_text=gen.SYSTEM, scene_text=gen.SCENE)
+    app.setResolution(32, 32)
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    ref.setTraceMode(False)
+    o_tbg, o_ids = ref.traceRays(rays)
+    assert np.array_equal(o_ids, ids) and np.array_equal(_bits(o_tbg[hit]), _bits(tbg[hit]))
+    _, s_ids = ref.traceRays(shadow, anyHit=True)
+    assert np.array_equal(s_ids[:, 0], occ[:, 0])
