@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/wide8_small_room.npz ON THE GPU BOX: the compressed 8-ary nodes and the triangle slots twk_build produced
-(TWK_WIDE8=1) for a small Cornell room (spheres 24 x 12), a fixed set of rays, and the hit records of the persistent kernel for
-them. The CPU suite walks this tree with oracle/same_bvh_walk.cpp (orc_walk_same_bvh8) and compares with the device's records
+"""Generates tests/golden/wide8_small_room.npz (and, with `4` as argument, wide4_small_room.npz: the quantised 4-ary nodes the
+product ships with) ON THE GPU BOX: the nodes and the triangle slots twk_build produced for a small Cornell room (spheres
+24 x 12), a fixed set of rays, and the hit records of the persistent kernel for them. The CPU suite walks this tree with oracle/same_bvh_walk.cpp (orc_walk_same_bvh8) and compares with the device's records
 and with the oracle's brute force over the same scene (tests/test_oracle_golden.py). Data only: arrays.
-usage (GPU box): TWK_WIDE8=1 python tests/golden/make_wide8_fixture.py"""
+usage (GPU box): python tests/golden/make_wide8_fixture.py [8|4]"""
 import os
 import sys
 
@@ -11,7 +11,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["TWK_WIDE8"] = "1"
+WIDTH = 4 if (len(sys.argv) > 1 and sys.argv[1] == "4") else 8
+if __name__ == "__main__":
+    os.environ["TWK_WIDE8"] = "1" if WIDTH == 8 else "0"
+    os.environ["TWK_TILE_ENTRIES"] = "0"
 import tweeker_raytracer_amd as twk  # noqa: E402
 
 SYSTEM = open(os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box.txt")).read()
@@ -38,14 +41,15 @@ if __name__ == "__main__":
     dev = twk.Device(ordinal=0, miss=app.info.miss)
     app.initDevice(dev)
     info, nodes, tris, inst = dev.readAcceleration()
-    assert info["nodeFloats"] == 20 and info["root"] == 0
+    assert info["nodeFloats"] == (20 if WIDTH == 8 else 16)
     rays = fixture_rays()
     dev.statsEnable(True)
     dev.statsGet(True)
     rec, instance, _ = dev.debugTraceQueue(rays, None)
     st = dev.statsGet(True)
     prim = np.where(instance >= 0, tris[:, 3].view(np.int32)[np.maximum(rec[:, 3].view(np.int32), 0)], -1).astype(np.int32)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "wide8_small_room.npz"), nodes=nodes, triangles=tris, rays=rays,
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "wide%d_small_room.npz" % WIDTH), nodes=nodes, triangles=tris, rays=rays,
+                        root=np.int32(info["root"]), root2=np.int32(info["root2"]),
                         device_tbg=rec[:, :3].copy(), device_instance=instance.astype(np.int32), device_primitive=prim,
                         device_nodes_visited=np.int64(st["nodesVisited"]), device_triangles_tested=np.int64(st["trianglesTested"]))
     print("nodes", nodes.shape, "triangles", tris.shape, "hits", int((instance >= 0).sum()), "of", rays.shape[0], "visits", st["nodesVisited"], st["trianglesTested"])
