@@ -267,6 +267,7 @@ static void refreshParams(TwkDevice dev)
   // seven trace blocks per CU where the variant that fits them applies (device_types.h TWK_TRACE_WAVES7)
   p.traceWaves = (!dev->twoLevel && (!p.hasCutout || TWK_TRACE_WAVES_CUTOUT == TWK_TRACE_WAVES7) && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : (p.hasCutout ? (dev->twoLevel ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES) : TWK_TRACE_WAVES);
   if (dev->traceWavesForced == TWK_TRACE_WAVES || (dev->traceWavesForced == TWK_TRACE_WAVES7 && !dev->twoLevel)) p.traceWaves = dev->traceWavesForced;
+  if (p.hasCutout && p.wide8 != nullptr && p.traceWaves == TWK_TRACE_WAVES7) p.traceWaves = TWK_TRACE_WAVES; // the 8-ary cutout build has no seven-block form (trace_kernels8.hip)
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)
   {
@@ -1058,6 +1059,7 @@ try
 {
   int rc = activate(dev, "twk_build"); if (rc) return rc;
   if (dev->geometries.empty() || dev->instances.empty()) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_build: the scene has no geometry or no instance");
+  dev->built = false; // until this build has succeeded: a failure below leaves no half-built scene to launch on
   const auto buildStart = std::chrono::steady_clock::now();
   TwkBuildInfo info;
   memset(&info, 0, sizeof(info));
