@@ -29,7 +29,8 @@ extern "C" {
  * twk_debug_read_acceleration hands out the 64-byte quantised wide nodes instead of 128-byte ones. */
 /* 8: TwkBuildInfo grew by wide8Nodes / wide8Levels; TwkAccelerationInfo.reserved became nodeFloats — twk_debug_read_acceleration
  * hands out the compressed 8-ary nodes (20 floats each) where the persistent kernel walks those. */
-#define TWK_ABI_VERSION 8
+/* 9: TwkLaunchStats grew by the shade kernel's per-phase tallies; twk_set_next_event_estimation, twk_set_debug_exceptions. */
+#define TWK_ABI_VERSION 9
 
 typedef enum TwkResult
 {
@@ -162,7 +163,36 @@ typedef struct TwkLaunchStats
    * summed over all waves, per phase of the kernel's outer loop — [0] refill (ray fetch), [1] node loop, [2] leaf /
    * instance step, [3] triangle loop, [4] pop + result write, [5] whole kernel. */
   uint64_t waveCycles[6];
+  /* ABI 9. Where the waves of the shade kernel spend their instructions and their time, per phase of the shading of a path segment
+   * (TWK_SHADE_PHASE_*): how often a wave ran the phase, with how many of its 64 lanes (lane occupancy of the phase = lanes /
+   * (64 x wave steps)), and for how many shader-clock cycles (waits included). */
+  uint64_t shadePhaseWaveSteps[24];
+  uint64_t shadePhaseLanes[24];
+  uint64_t shadePhaseCycles[24];
 } TwkLaunchStats;
+#define TWK_SHADE_PHASE_COUNT 24
+/* index into TwkLaunchStats::shadePhase*: */
+enum
+{
+  TWK_SHADE_PHASE_PATH = 0,          /* the whole shading of a segment */
+  TWK_SHADE_PHASE_VOLUME_FETCH = 1,  /* volume stack top of a path inside a medium */
+  TWK_SHADE_PHASE_MISS = 2,          /* miss programs (miss.cu) */
+  TWK_SHADE_PHASE_HIT_RECORD = 3,    /* instance, shading record, material; normals; front face (closesthit.cu:126-186) */
+  TWK_SHADE_PHASE_TANGENT = 4,       /* GGX materials: tangent */
+  TWK_SHADE_PHASE_TEXCOORD = 5,      /* textured materials */
+  TWK_SHADE_PHASE_LIGHT_HIT = 6,     /* implicit light hit (closesthit.cu:192-222) */
+  TWK_SHADE_PHASE_BSDF_DIFFUSE = 7, TWK_SHADE_PHASE_BSDF_MIRROR = 8, TWK_SHADE_PHASE_BSDF_GLASS = 9,
+  TWK_SHADE_PHASE_BSDF_GGX = 10, TWK_SHADE_PHASE_BSDF_GGX_GLASS = 11, /* the five sample callables */
+  TWK_SHADE_PHASE_NEE_SAMPLE = 12,   /* draws + light sampler (closesthit.cu:252-264) */
+  TWK_SHADE_PHASE_NEE_EVAL = 13,     /* BSDF eval + contribution (closesthit.cu:266-299) */
+  TWK_SHADE_PHASE_RADIANCE = 14,     /* read-modify-write of the path's radiance */
+  TWK_SHADE_PHASE_TAIL = 15,         /* integrator loop tail (raygeneration.cu:91-146) */
+  TWK_SHADE_PHASE_VOLUME_PUSH = 16,  /* glass transmission: volume stack push / pop */
+  TWK_SHADE_PHASE_AOV = 17,          /* denoiser AOV writes */
+  TWK_SHADE_PHASE_KERNEL_LOAD = 18,  /* wait for the queue slot's streams */
+  TWK_SHADE_PHASE_KERNEL_APPEND = 19,/* queue appends: ballots, barriers, the block's atomic, the stores (lanes = appending lanes) */
+  TWK_SHADE_PHASE_KERNEL_ITERATION = 20 /* one block iteration of the kernel, per wave (lanes = lanes with a queue slot) */
+};
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */
 enum
@@ -279,6 +309,15 @@ int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats);
  * traversal and shade launch are summed (lanes of a wave wait for each other in both designs). Measurement builds of the
  * kernels run while it is on (as with twk_stats_enable): it is a diagnostic view, not a fast path. */
 int twk_set_time_view(TwkDevice dev, int enable);
+
+/* ABI 9. ≙ the reference's compile-time lighting switch USE_NEXT_EVENT_ESTIMATION (shaders/config.h:50-52), a run-time switch
+ * here: 1 (default) = next-event estimation per path vertex with power-heuristic MIS; 0 = brute-force path tracing — no light
+ * sample, no shadow ray (closesthit.cu:250-304), implicit light and environment hits unweighted (closesthit.cu:202-214,
+ * miss.cu:62-68,92-106). Both estimate the same image; the reference keeps the switch "to compare lighting results". */
+int twk_set_next_event_estimation(TwkDevice dev, int enable);
+/* ABI 9. ≙ USE_DEBUG_EXCEPTIONS of the ray generation program (config.h:54-56, raygeneration.cu:205-218): 1 = a sample that is
+ * NaN / infinite / negative is accumulated as super red / green / blue (1e6) instead of NaN samples being dropped; 0 (default). */
+int twk_set_debug_exceptions(TwkDevice dev, int enable);
 
 /* Output. With distribution 0 the buffer is W×H (≙ outputBuffer); with distribution 1 it is the
  * packed launchWidth×H local tile buffer (≙ texelBuffer, DeviceMultiGPULocalCopy.cpp:109-172). */

@@ -29,5 +29,6 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 #endif
 #define __hip_atomic_fetch_add(ptr, value, order, scope) ((*(ptr)) += (value))
 using std::isnan;
+using std::isinf;
 using std::min;
 using std::max;

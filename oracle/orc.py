@@ -11,6 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_PATH = os.path.join(_HERE, "liboracle.so")
 ORACLE_LIBM_PATH = os.path.join(_HERE, "liboracle_libm.so")
+ORACLE_NEE0_PATH = os.path.join(_HERE, "liboracle_nee0.so")      # built with -DUSE_NEXT_EVENT_ESTIMATION=0 (config.h:50-52)
+ORACLE_DBGEXC_PATH = os.path.join(_HERE, "liboracle_dbgexc.so")  # built with -DUSE_DEBUG_EXCEPTIONS=1 (config.h:54-56)
 REF_PATH = os.path.join(_HERE, "_ref", "libref_host.so")
 
 
@@ -31,8 +33,9 @@ def _f(a):
 class Oracle:
     """Same call sequence as tweeker_raytracer_amd.Device, executed by the CPU restatement."""
 
-    def __init__(self, index=0, count=1, miss=1, libm=False):
-        self.lib = _load(ORACLE_LIBM_PATH if libm else ORACLE_PATH)
+    def __init__(self, index=0, count=1, miss=1, libm=False, nee=True, debugExceptions=False):
+        assert not (libm and (not nee or debugExceptions)) and not (not nee and debugExceptions), "one compile-time switch per oracle build"
+        self.lib = _load(ORACLE_LIBM_PATH if libm else (ORACLE_NEE0_PATH if not nee else (ORACLE_DBGEXC_PATH if debugExceptions else ORACLE_PATH)))
         self.lib.orc_last_error.restype = C.c_char_p
         self._h = C.c_void_p()
         self._chk(self.lib.orc_create(C.byref(self._h), int(index), int(count), int(miss)))

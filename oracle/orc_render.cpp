@@ -15,6 +15,17 @@
 #include <thread>
 #include <cmath>
 
+// The reference's compile-time switches (apps/rtigo3/shaders/config.h:50-60), resolved at compile time here too: the Makefile
+// builds liboracle.so with the defaults and liboracle_nee0.so / liboracle_dbgexc.so with one of them flipped
+// (orc.Oracle(nee=False) / orc.Oracle(debugExceptions=True)); the product has them as run-time switches
+// (twk_set_next_event_estimation, twk_set_debug_exceptions).
+#ifndef USE_NEXT_EVENT_ESTIMATION
+#define USE_NEXT_EVENT_ESTIMATION 1
+#endif
+#ifndef USE_DEBUG_EXCEPTIONS
+#define USE_DEBUG_EXCEPTIONS 0
+#endif
+
 namespace orc {
 
 struct Oracle
@@ -212,8 +223,12 @@ static void missProgram(const Oracle& o, PerRayData* thePrd)
     default:
     case 1:
     {
+#if USE_NEXT_EVENT_ESTIMATION
       const float weightMIS = (thePrd->flags & FLAG_DIFFUSE) ? powerHeuristic(thePrd->pdf, 0.25f * M_1_PIf_) : 1.0f;
       thePrd->radiance = make_float3(weightMIS);
+#else
+      thePrd->radiance = make_float3(1.0f);
+#endif
       thePrd->albedo   = make_float3(1.0f); // Optix7Gui miss.cu:67-71
       thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
       break;
@@ -225,6 +240,7 @@ static void missProgram(const Oracle& o, PerRayData* thePrd)
       const float theta = pm_acosf(-R.y);
       const float v     = theta * M_1_PIf_;
       const float3 emission = make_float3(tex2D(sysData.textures[2], u, v));
+#if USE_NEXT_EVENT_ESTIMATION
       float weightMIS = 1.0f;
       if (thePrd->flags & FLAG_DIFFUSE)
       {
@@ -232,6 +248,9 @@ static void missProgram(const Oracle& o, PerRayData* thePrd)
         weightMIS = powerHeuristic(thePrd->pdf, pdfLight);
       }
       thePrd->radiance = emission * weightMIS;
+#else
+      thePrd->radiance = emission;
+#endif
       thePrd->albedo   = emission;          // Optix7Gui miss.cu:105-109
       thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
       break;
@@ -291,11 +310,13 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
     {
       LightDefinition const& light = sysData.lightDefinitions[hc.inst->light];
       emission = light.emission;
+#if USE_NEXT_EVENT_ESTIMATION
       const float lightPdf = (thePrd->distance * thePrd->distance) / (light.area * cosTheta);
       if ((thePrd->flags & FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
       {
         emission *= powerHeuristic(thePrd->pdf, lightPdf);
       }
+#endif
     }
     thePrd->radiance = emission;
     thePrd->albedo   = emission;
@@ -310,11 +331,13 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
     {
       LightDefinition const& light = sysData.lightDefinitions[hc.inst->light];
       float3 emission = light.emission;
+#if USE_NEXT_EVENT_ESTIMATION
       const float lightPdf = (thePrd->distance * thePrd->distance) / (light.area * cosTheta);
       if ((thePrd->flags & FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
       {
         emission *= powerHeuristic(thePrd->pdf, lightPdf);
       }
+#endif
       thePrd->radiance = emission;
       thePrd->albedo   = emission;
       thePrd->flags |= FLAG_LIGHT | FLAG_TERMINATE;
@@ -340,6 +363,7 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
 
   callBsdfSample(material.indexBSDF, material, state, thePrd);
 
+#if USE_NEXT_EVENT_ESTIMATION
   const int numLights = sysData.numLights;
   if ((thePrd->flags & FLAG_DIFFUSE) && 0 < numLights)
   {
@@ -372,6 +396,7 @@ static void closesthitRadiance(Oracle& o, const HitContext& hc, PerRayData* theP
       }
     }
   }
+#endif
 }
 
 // raygeneration.cu:42-149
@@ -524,7 +549,22 @@ static void raygenPathTracer(Oracle& o, unsigned int lx, unsigned int ly)
   float3 radiance = integrator(o, prd, o.captureFirstHits ? &o.firstHits[index] : nullptr, albedo, normal);
   rayTally().samples++;
 
+#if USE_DEBUG_EXCEPTIONS
+  if (std::isnan(radiance.x) || std::isnan(radiance.y) || std::isnan(radiance.z))
+  {
+    radiance = make_float3(1000000.0f, 0.0f, 0.0f);
+  }
+  else if (std::isinf(radiance.x) || std::isinf(radiance.y) || std::isinf(radiance.z))
+  {
+    radiance = make_float3(0.0f, 1000000.0f, 0.0f);
+  }
+  else if (radiance.x < 0.0f || radiance.y < 0.0f || radiance.z < 0.0f)
+  {
+    radiance = make_float3(0.0f, 0.0f, 1000000.0f);
+  }
+#else
   if (!(std::isnan(radiance.x) || std::isnan(radiance.y) || std::isnan(radiance.z)))
+#endif
   {
     if (0 < sysData.iterationIndex)
     {

@@ -24,7 +24,7 @@ def test_header_python_binding_and_library_agree(twk):
     assert exported == declared, set(exported) ^ set(declared)
     for name in declared:
         assert getattr(_lib.lib, name) is not None
-    assert _lib.lib.twk_abi_version() == 8
+    assert _lib.lib.twk_abi_version() == 9
 
 
 def test_no_gpu_means_loud_failure_not_fallback(twk):

@@ -162,14 +162,34 @@ def read(path):
         return preprocess(f.read())
 
 
-@pytest.fixture(scope="module")
-def texts():
+def load_texts():
     t = {name: read(os.path.join(REF, name)) for name in
          ("bxdf_diffuse.cu", "bxdf_specular.cu", "bxdf_ggx_smith.cu", "light_sample.cu", "miss.cu", "lens_shader.cu", "closesthit.cu",
           "raygeneration.cu", "shader_common.h", "random_number_generators.h", "anyhit.cu")}
     t["orc_shaders"] = read(os.path.join(ROOT, "oracle", "orc_shaders.h"))
     t["orc_render"] = read(os.path.join(ROOT, "oracle", "orc_render.cpp"))
     return t
+
+
+@pytest.fixture(scope="module")
+def texts():
+    return load_texts()
+
+
+class flipped:
+    """`with flipped(USE_NEXT_EVENT_ESTIMATION=0):` — both texts are preprocessed with that config.h value (the oracle carries the
+    reference's #if blocks and is compiled once per value: oracle/Makefile liboracle_nee0.so, liboracle_dbgexc.so)."""
+
+    def __init__(self, **values):
+        self.values = values
+
+    def __enter__(self):
+        self.saved = dict(DEFINES)
+        DEFINES.update(self.values)
+
+    def __exit__(self, *exc):
+        DEFINES.clear()
+        DEFINES.update(self.saved)
 
 
 # (reference file, reference function, oracle file, oracle function)
@@ -392,7 +412,7 @@ def test_anyhit_programs(texts):
     assert "if(!anyhitRadianceCutout(o,hc,prd->seed))" in stmts(function_body(orc_text, "traceRadiance"))
 
 
-RAYGEN_RENAMES = REF_RENAMES + [(r"theLaunchIndex\.x", "lx"), (r"theLaunchIndex\.y", "ly"), (r"\bisnan\(", "std::isnan("), (r"\bbuffer\[index\]", "o.output[index]")]
+RAYGEN_RENAMES = REF_RENAMES + [(r"theLaunchIndex\.x", "lx"), (r"theLaunchIndex\.y", "ly"), (r"\bisnan\(", "std::isnan("), (r"\bisinf\(", "std::isinf("), (r"\bbuffer\[index\]", "o.output[index]")]
 RAYGEN_MAP = {
     "const uint2 theLaunchIndex=make_uint2(optixGetLaunchIndex());": "const SystemData&sysData=o.sys;",   # lx, ly are parameters
     "unsigned int launchColumn=lx;": ["unsigned int launchColumn=lx;", "const bool tiled=(sysData.distribution&&1<sysData.deviceCount);"],
@@ -526,3 +546,30 @@ def test_screenshot_tonemap_loop(texts):
     })
     orc = stmts(function_body(texts["orc_render"], "screenshotTonemap"))
     assert orc == ref, _diff(ref, orc)
+
+
+# =====================================================================================================================
+# Round 5: the reference's compile-time lighting switch and its debug filter (shaders/config.h:50-56). The oracle carries
+# the same #if blocks; the programs they touch are compared again with each switch flipped.
+# =====================================================================================================================
+def test_next_event_estimation_off():
+    """USE_NEXT_EVENT_ESTIMATION 0: closesthit.cu:202-214,250-304, miss.cu:62-68,92-106, Optix7Gui closesthit.cu:202-214."""
+    with flipped(USE_NEXT_EVENT_ESTIMATION=0):
+        t = load_texts()
+        ref = statements(function_body(t["closesthit.cu"], "__closesthit__radiance"), REF_RENAMES)
+        assert not any("lightSample" in x or "powerHeuristic" in x for x in ref), "the reference's brute-force build samples no light"
+        orc = statements(function_body(t["orc_render"], "closesthitRadiance"))
+        assert not any("lightSample" in x or "powerHeuristic" in x or "traceShadow" in x for x in orc)
+        test_closesthit_radiance(t)
+        test_miss_programs(t)
+        test_integrator_loop(t)
+        test_optix7gui_light_block(t)
+
+
+def test_debug_exceptions_on():
+    """USE_DEBUG_EXCEPTIONS 1: raygeneration.cu:205-218 — the false-colour filter replaces the NaN filter."""
+    with flipped(USE_DEBUG_EXCEPTIONS=1):
+        t = load_texts()
+        ref = stmts(function_body(t["raygeneration.cu"], "__raygen__path_tracer"), RAYGEN_RENAMES, CASTS)
+        assert "radiance=make_float3(0.0f,0.0f,1000000.0f);" in ref
+        test_raygen_path_tracer(t)

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs bench.py (no CPU baseline) for each "name[:ENV=VALUE]" argument: name = build/lib_<name>.so variant ("base" = the in-tree library).
-# usage (GPU box): bash tools/ab_run.sh base base:TWK_MAX_LEAF=3 k32 ...
+# usage (GPU box): [STEPS=20 WARMUP=5] bash tools/ab_run.sh base base:TWK_MAX_LEAF=3 k32 ...
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
   [[ "$spec" == *:* ]] && envs=${spec#*:}
   lib=""; [[ "$name" != "base" ]] && lib="TWK_LIB=build/lib_$name.so"
-  out=gpurun_out/ab_${spec//[:=]/_}.json
-  env $lib ${envs//,/ } timeout -k 10 200 python bench.py --no-cpu-baseline > $out 2>/dev/null
+  out=gpurun_out/ab_${spec//[:=]/_}_s${STEPS:-64}.json
+  env $lib ${envs//,/ } timeout -k 10 200 python bench.py --no-cpu-baseline --steps ${STEPS:-64} --warmup ${WARMUP:-4} > $out 2>/dev/null
   python - "$spec" "$out" <<'PY'
 import json, sys
 try:

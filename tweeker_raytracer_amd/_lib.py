@@ -70,7 +70,8 @@ class LaunchStats(C.Structure):
                 ("tailNodesVisited", C.c_uint64), ("tailTrianglesTested", C.c_uint64), ("tailInstancesEntered", C.c_uint64),
                 ("overflowRays", C.c_uint64),
                 ("nodeWaveSteps", C.c_uint64), ("triangleWaveSteps", C.c_uint64), ("leafWaveSteps", C.c_uint64),
-                ("cachedNodesVisited", C.c_uint64), ("droppedStackPushes", C.c_uint64), ("waveCycles", C.c_uint64 * 6)]
+                ("cachedNodesVisited", C.c_uint64), ("droppedStackPushes", C.c_uint64), ("waveCycles", C.c_uint64 * 6),
+                ("shadePhaseWaveSteps", C.c_uint64 * 24), ("shadePhaseLanes", C.c_uint64 * 24), ("shadePhaseCycles", C.c_uint64 * 24)]
 
 
 class AccelerationInfo(C.Structure):
@@ -102,7 +103,7 @@ SYMBOLS = [
     "twk_set_state", "twk_init_cameras", "twk_init_lights", "twk_init_materials", "twk_update_camera",
     "twk_update_light", "twk_update_material", "twk_init_texture", "twk_add_geometry", "twk_add_instance",
     "twk_build", "twk_clear_scene", "twk_set_flatten_policy", "twk_set_build_quality", "twk_get_build_info", "twk_launch", "twk_sync", "twk_set_launch_batch", "twk_reserve_launch_batch", "twk_get_launch_width", "twk_read_output",
-    "twk_set_shader_variant", "twk_enable_aov", "twk_read_aov", "twk_set_time_view", "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_set_shared_frame", "twk_compositor", "twk_tonemap", "twk_profile_enable",
+    "twk_set_shader_variant", "twk_enable_aov", "twk_read_aov", "twk_set_time_view", "twk_set_next_event_estimation", "twk_set_debug_exceptions", "twk_get_output_device_pointer", "twk_set_output_device_pointer", "twk_set_shared_frame", "twk_compositor", "twk_tonemap", "twk_profile_enable",
     "twk_profile_reset", "twk_profile_get", "twk_stats_enable", "twk_stats_get", "twk_stream_peak_gbps", "twk_gather_peak",
     "twk_debug_capture", "twk_debug_read_first_hits", "twk_trace_rays", "twk_debug_trace_queue", "twk_debug_read_acceleration", "twk_debug_snapshot_scene", "twk_debug_math",
     "twk_app_create", "twk_app_create_from_strings", "twk_app_destroy", "twk_app_info", "twk_app_set_resolution",

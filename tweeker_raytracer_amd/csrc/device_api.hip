@@ -88,6 +88,7 @@ struct TileEntriesKey
   uint64_t buildSerial;
 };
 #define TWK_MAX_LANES 4
+#define TWK_STATS_WORDS 192 // device words of TwkLaunchStats: [0, 24) traversal + shade totals, [24, 96) the shade phases (shade_device.h PhaseScope); twice: the time view's scratch copy
 #define TWK_COUNTER_WORDS (TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)) // one lane's counter block
 
 struct TwkDevice_t
@@ -142,6 +143,7 @@ struct TwkDevice_t
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
   // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
   bool aovEnabled = false; int shaderVariant = TWK_SHADERS_RTIGO3;
+  bool nextEventEstimation = true, debugExceptions = false; // twk_set_next_event_estimation / twk_set_debug_exceptions (≙ shaders/config.h:50-56)
   bool timeView = false; float* d_pathTime = nullptr; int timePaths = 0; // twk_set_time_view
   float4* d_pathAlbedo = nullptr; float4* d_pathNormal = nullptr; int aovPaths = 0;
   float4* d_aovAlbedo = nullptr; float4* d_aovNormal = nullptr; int aovPixels = 0;
@@ -289,9 +291,10 @@ static void refreshParams(TwkDevice dev)
   p.outputFrame = (dev->d_outputExternal && dev->outputFrame) ? 1 : 0;
   p.counters = dev->d_counters;
   // the time view runs the measurement builds of the kernels, which tally: into a scratch block unless statistics are on
-  p.stats = dev->statsEnabled ? dev->d_stats : (dev->timeView ? dev->d_stats + 24 : nullptr);
+  p.stats = dev->statsEnabled ? dev->d_stats : (dev->timeView ? dev->d_stats + TWK_STATS_WORDS / 2 : nullptr);
   p.pathTime = dev->timeView ? dev->d_pathTime : nullptr; p.clockScale = dev->state.clockFactor * 1.0e-9f; // Device.h:350 CLOCK_FACTOR_SCALE
   p.shaderVariant = dev->shaderVariant;
+  p.nextEventEstimation = dev->nextEventEstimation ? 1 : 0; p.debugExceptions = dev->debugExceptions ? 1 : 0;
   p.pathAlbedo = dev->aovEnabled ? dev->d_pathAlbedo : nullptr; p.pathNormal = dev->aovEnabled ? dev->d_pathNormal : nullptr;
   p.aovAlbedo  = dev->aovEnabled ? dev->d_aovAlbedo : nullptr;  p.aovNormal  = dev->aovEnabled ? dev->d_aovNormal : nullptr;
   p.firstHit = dev->captureFirstHits ? dev->d_firstHit : nullptr;
@@ -367,7 +370,7 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     }
   }
   if (!dev->d_counters) HIP_TRY(hipMalloc(&dev->d_counters, sizeof(unsigned int) * TWK_COUNTER_WORDS * TWK_MAX_LANES));
-  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * 48)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * 48, dev->stream)); } // TwkLaunchStats words + a scratch block for the time view
+  if (!dev->d_stats) { HIP_TRY(hipMalloc(&dev->d_stats, sizeof(unsigned long long) * TWK_STATS_WORDS)); HIP_TRY(hipMemsetAsync(dev->d_stats, 0, sizeof(unsigned long long) * TWK_STATS_WORDS, dev->stream)); } // TwkLaunchStats words (24 + the shade phases' 3 x 24) + a scratch block of the same size for the time view
   if (!dev->h_dropped)
   {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->h_dropped), sizeof(unsigned int), hipHostMallocMapped));
@@ -1406,6 +1409,26 @@ try
 }
 TWK_CATCH("twk_set_time_view")
 
+int twk_set_next_event_estimation(TwkDevice dev, int enable)
+try
+{
+  int rc = activate(dev, "twk_set_next_event_estimation"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->nextEventEstimation = (enable != 0);
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_set_next_event_estimation")
+
+int twk_set_debug_exceptions(TwkDevice dev, int enable)
+try
+{
+  int rc = activate(dev, "twk_set_debug_exceptions"); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  dev->debugExceptions = (enable != 0);
+  return TWK_SUCCESS;
+}
+TWK_CATCH("twk_set_debug_exceptions")
+
 int twk_read_aov(TwkDevice dev, int which, float* rgbaHost, size_t numFloats)
 try
 {
@@ -1546,7 +1569,7 @@ try
   memset(stats, 0, sizeof(*stats));
   if (!dev->d_stats) return TWK_SUCCESS;
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  unsigned long long h[24];
+  unsigned long long h[TWK_STATS_WORDS / 2];
   HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
@@ -1554,6 +1577,8 @@ try
   stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
   stats->cachedNodesVisited = h[16]; stats->droppedStackPushes = dev->h_dropped ? *dev->h_dropped : 0u;
   for (int i = 0; i < 6; ++i) stats->waveCycles[i] = h[18 + i];
+  const int TWK_SHADE_PHASES = TWK_SHADE_PHASE_COUNT; static_assert(24 + 3 * TWK_SHADE_PHASE_COUNT <= TWK_STATS_WORDS / 2, "shade phase words"); // shade_device.h asserts TWK_SHADE_PHASES == TWK_SHADE_PHASE_COUNT
+  for (int i = 0; i < TWK_SHADE_PHASES; ++i) { stats->shadePhaseWaveSteps[i] = h[24 + i]; stats->shadePhaseLanes[i] = h[24 + TWK_SHADE_PHASES + i]; stats->shadePhaseCycles[i] = h[24 + 2 * TWK_SHADE_PHASES + i]; }
   if (reset) HIP_TRY(hipMemset(dev->d_stats, 0, sizeof(h)));
   return TWK_SUCCESS;
 }

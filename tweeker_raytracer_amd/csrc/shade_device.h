@@ -49,6 +49,63 @@ struct SurfaceState // per_ray_data.h:74-81
   V3 normalGeo, tangent, normal, texcoord, albedo;
 };
 
+// Measurement builds of shadeKernel (MEASURE: twk_stats_enable, time view): for every phase of shadePath — how often a wave ran it,
+// with how many of its lanes, and for how many shader-clock cycles (waits included). Tallied by the phase's first active lane in
+// LDS words of the block ([0, N) wave executions, [N, 2N) lanes, [2N, 3N) cycles), flushed once per block to
+// TwkLaunchStats::shadePhase*. Lane occupancy of a phase = lanes / (64 x wave executions). Compiled out of every other build.
+#define TWK_SHADE_PHASES 24
+static_assert(TWK_SHADE_PHASES == TWK_SHADE_PHASE_COUNT, "include/tweeker_hip.h TwkLaunchStats::shadePhase*");
+enum ShadePhase
+{
+  SP_PATH = 0,        // the whole of shadePath
+  SP_VOLUME_FETCH,    // volume stack top of a path inside a medium
+  SP_MISS,            // miss programs
+  SP_HIT_RECORD,      // instance + shading record + material, normals, front face
+  SP_TANGENT,         // GGX only: tangent fetch + transform
+  SP_TEXCOORD,        // textured materials only
+  SP_LIGHT_HIT,       // emission + MIS weight of an implicit light hit
+  SP_BSDF_DIFFUSE, SP_BSDF_MIRROR, SP_BSDF_GLASS, SP_BSDF_GGX, SP_BSDF_GGX_GLASS, // the five sample callables
+  SP_NEE_SAMPLE,      // draws + light sampler
+  SP_NEE_EVAL,        // BSDF eval + contribution of a usable light sample
+  SP_RADIANCE,        // read-modify-write of the path's radiance word
+  SP_TAIL,            // integrator loop tail: absorption, Russian roulette, volume stack, outputs
+  SP_VOLUME_PUSH,     // glass transmission: push / pop of the volume stack
+  SP_AOV,             // denoiser AOV writes
+  SP_KERNEL_LOAD,     // shadeKernel: wait for the slot's streams (first use of the prefetched registers)
+  SP_KERNEL_APPEND,   // shadeKernel: ballots, the block's two barriers and returning atomic, the queue writes
+  SP_KERNEL_ITERATION // shadeKernel: one block iteration, everything included
+};
+template<bool MEASURE> struct PhaseScope
+{
+  TWK_D PhaseScope(unsigned int*, int) {}
+  TWK_D void end() {}
+};
+#if defined(__HIPCC__)
+template<> struct PhaseScope<true>
+{
+  unsigned int* word;
+  unsigned int t0;
+  TWK_D PhaseScope(unsigned int* lds, int phase)
+  {
+    const unsigned long long mask = __ballot(1);
+    word = nullptr;
+    if ((threadIdx.x & 63u) == (unsigned int) (__ffsll((long long) mask) - 1))
+    {
+      word = lds + phase;
+      atomicAdd(word, 1u);
+      atomicAdd(word + TWK_SHADE_PHASES, (unsigned int) __popcll(mask));
+    }
+    t0 = (unsigned int) __builtin_readcyclecounter();
+  }
+  TWK_D void end() // a phase that ends before its scope does
+  {
+    const unsigned int now = (unsigned int) __builtin_readcyclecounter();
+    if (word != nullptr) { atomicAdd(word + 2 * TWK_SHADE_PHASES, now - t0); word = nullptr; }
+  }
+  TWK_D ~PhaseScope() { end(); }
+};
+#endif
+
 TWK_D float4 tex2D(const DevTexture& tex, float u, float v)
 {
   const int W = tex.width, H = tex.height;
@@ -224,13 +281,15 @@ TWK_D float distribution_G(const float ax, const float ay, const V3& wo, const V
 }
 
 // Sample callables, dispatched on MaterialDefinition::indexBSDF (closesthit.cu:246-248).
-TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, PathPrd& prd)
+template<bool MEASURE = false>
+TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, PathPrd& prd, unsigned int* phaseLds = nullptr)
 {
   switch (material.indexBSDF)
   {
     default:
     case 0: // bxdf_diffuse.cu:67-86
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_BSDF_DIFFUSE);
       const float sx = rng(prd.seed);
       const float sy = rng(prd.seed);
       unitSquareToCosineHemisphere(sx, sy, state.normal, prd.wi, prd.pdf);
@@ -241,6 +300,7 @@ TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, Pa
     }
     case 1: // bxdf_specular.cu:71-83
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_BSDF_MIRROR);
       prd.wi = reflect(-prd.wo, state.normal);
       if (dot(prd.wi, state.normalGeo) <= 0.0f) { prd.flags |= TWK_FLAG_TERMINATE; return; }
       prd.f_over_pdf = state.albedo;
@@ -249,6 +309,7 @@ TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, Pa
     }
     case 2: // bxdf_specular.cu:94-134
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_BSDF_GLASS);
       prd.absorption_ior = make_float4(material.absorption[0], material.absorption[1], material.absorption[2], material.ior);
       const float eta = (prd.flags & (TWK_FLAG_FRONTFACE | TWK_FLAG_THINWALLED)) ? prd.absorption_ior.w / prd.iorX : prd.iorY / prd.absorption_ior.w;
       const V3 R = reflect(-prd.wo, state.normal);
@@ -267,6 +328,7 @@ TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, Pa
     }
     case 3: // bxdf_ggx_smith.cu:169-222
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_BSDF_GGX);
       const float sx = rng(prd.seed);
       const float sy = rng(prd.seed);
       const V3 wm = distribution_sample(material.roughness[0], material.roughness[1], sx, sy);
@@ -289,6 +351,7 @@ TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, Pa
     }
     case 4: // bxdf_ggx_smith.cu:265-319
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_BSDF_GGX_GLASS);
       prd.absorption_ior = make_float4(material.absorption[0], material.absorption[1], material.absorption[2], material.ior);
       const float eta = (prd.flags & (TWK_FLAG_FRONTFACE | TWK_FLAG_THINWALLED)) ? prd.absorption_ior.w / prd.iorX : prd.iorY / prd.absorption_ior.w;
       const float sx = rng(prd.seed);
@@ -473,10 +536,12 @@ struct ShadeOutput
 // (the full kernel spills 9 dwords), 30 instead of 36 KB of code; measured on C2: shade 0.290 -> 0.273 ms per step.
 // PRIMARY: the first segment of a path whose generateKernel was skipped (shade_kernels.hip "primary rays"): this call owns the
 // path's radiance and AOV words and initialises them (raygeneration.cu:53-62) instead of adding to them.
-template<bool ENV = true, bool TEX = true, bool PRIMARY = false>
+// MEASURE: the measurement build (PhaseScope above); phaseLds = the block's tally words.
+template<bool ENV = true, bool TEX = true, bool PRIMARY = false, bool MEASURE = false>
 TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth, unsigned int pixel, const float4& ro, const float4& rd,
-                     const float4& hit, int instanceIndex, ShadeOutput& out)
+                     const float4& hit, int instanceIndex, ShadeOutput& out, unsigned int* phaseLds = nullptr)
 {
+  PhaseScope<MEASURE> phasePath(phaseLds, SP_PATH);
   if (PRIMARY && p.pathAlbedo != nullptr)
   {
     p.pathAlbedo[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // Optix7Gui raygeneration.cu:66-71: black, null vector
@@ -503,6 +568,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   prd.radiance = v3(0.0f);
   if (TWK_MATERIAL_STACK_FIRST <= stackIdx)
   {
+    PhaseScope<MEASURE> phase(phaseLds, SP_VOLUME_FETCH);
     prd.flags |= TWK_FLAG_VOLUME;
     const float4 top = p.volumeStack[(size_t) stackIdx * p.numPaths + pixel];
     prd.sigma_t = v3(top);
@@ -520,6 +586,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
 
   if (instanceIndex < 0)
   {
+    PhaseScope<MEASURE> phase(phaseLds, SP_MISS);
     // ---- miss programs, miss.cu
     if (p.miss == 0) { prd.radiance = v3(0.0f); }                                   // :41-52 (albedo 0)
     else if (ENV && p.miss == 2)                                                     // :75-109
@@ -530,7 +597,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
       const float v     = theta * kInvPi;
       const V3 emission = v3(tex2D(p.textures[2], u, v));
       float weightMIS = 1.0f;
-      if (prd.flags & TWK_FLAG_DIFFUSE)
+      if (p.nextEventEstimation && (prd.flags & TWK_FLAG_DIFFUSE))                   // miss.cu:92-106
       {
         const float pdfLight = intensity(emission) / p.envIntegral;
         weightMIS = powerHeuristic(prd.pdf, pdfLight);
@@ -540,7 +607,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
     }
     else                                                                             // :54-73
     {
-      const float weightMIS = (prd.flags & TWK_FLAG_DIFFUSE) ? powerHeuristic(prd.pdf, 0.25f * kInvPi) : 1.0f;
+      const float weightMIS = (p.nextEventEstimation && (prd.flags & TWK_FLAG_DIFFUSE)) ? powerHeuristic(prd.pdf, 0.25f * kInvPi) : 1.0f; // miss.cu:62-69
       prd.radiance = v3(weightMIS);
       aovAlbedo = v3(1.0f);                                                          // Optix7Gui miss.cu:67-69
     }
@@ -549,6 +616,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   else
   {
     // ---- __closesthit__radiance, closesthit.cu:126-305
+    PhaseScope<MEASURE> phaseHit(phaseLds, SP_HIT_RECORD);
     const DevInstance& inst = tables.instances[instanceIndex];
     // The slot's shading record (bvh_build.hip emitTrianglesKernel): geometric normal and vertex normals for every
     // hit; tangents and texture coordinates are fetched only by the materials that read them (the tangent feeds the
@@ -570,12 +638,14 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
     state.tangent  = v3(0.0f);
     if (needTangent)
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_TANGENT);
       const float4 s3 = sv[3], s4 = sv[4], s5 = sv[5];
       const V3 tg = v3(s3.x, s3.y, s3.z) * alpha + v3(s3.w, s4.x, s4.y) * beta + v3(s4.z, s4.w, s5.x) * gamma;
       state.tangent = normalize(transformVector(inst.objectToWorld, tg));
     }
     if (needTexcoord)
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_TEXCOORD);
       const float4 s5 = sv[5], s6 = sv[6], s7 = sv[7];
       state.texcoord = v3(s5.y, s5.z, s5.w) * alpha + v3(s6.x, s6.y, s6.z) * beta + v3(s6.w, s7.x, s7.y) * gamma;
     }
@@ -595,10 +665,12 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
     }
 
     aovNormal = state.normal; // Optix7Gui closesthit.cu:183-185: the normal on the side the ray looks at
+    phaseHit.end();
 
     bool lightHit = false;
     if (0 <= inst.light && p.shaderVariant == TWK_SHADERS_OPTIX7GUI)
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_LIGHT_HIT);
       // Optix7Gui closesthit.cu:189-226: a light ends the path whichever side is hit; black on the back face and edge-on
       V3 emission = v3(0.0f);
       const float cosTheta = dot(prd.wo, state.normalGeo);
@@ -606,10 +678,13 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
       {
         const DevLight& light = tables.lights[inst.light];
         emission = v3(light.emission[0], light.emission[1], light.emission[2]);
-        const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
-        if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
+        if (p.nextEventEstimation)                                                   // Optix7Gui closesthit.cu:202-214
         {
-          emission = emission * powerHeuristic(prd.pdf, lightPdf);
+          const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
+          if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
+          {
+            emission = emission * powerHeuristic(prd.pdf, lightPdf);
+          }
         }
       }
       prd.radiance = emission;
@@ -619,16 +694,20 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
     }
     else if (0 <= inst.light && (prd.flags & TWK_FLAG_FRONTFACE))
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_LIGHT_HIT);
       // rtigo3 closesthit.cu:192-222: only the lit side ends the path, a back-face hit falls through to the light's (black specular) BSDF
       const float cosTheta = dot(prd.wo, state.normalGeo);
       if (DENOMINATOR_EPSILON < cosTheta)
       {
         const DevLight& light = tables.lights[inst.light];
         V3 emission = v3(light.emission[0], light.emission[1], light.emission[2]);
-        const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
-        if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
+        if (p.nextEventEstimation)                                                   // closesthit.cu:202-214
         {
-          emission = emission * powerHeuristic(prd.pdf, lightPdf);
+          const float lightPdf = (prd.distance * prd.distance) / (light.area * cosTheta);
+          if ((prd.flags & TWK_FLAG_DIFFUSE) && DENOMINATOR_EPSILON < lightPdf)
+          {
+            emission = emission * powerHeuristic(prd.pdf, lightPdf);
+          }
         }
         prd.radiance = emission;
         aovAlbedo = emission;
@@ -652,20 +731,23 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
 
       prd.flags = (prd.flags & ~TWK_FLAG_DIFFUSE) | TWK_FLAG_HIT | material.flags;
 
-      sampleBsdf(material, state, prd);
+      sampleBsdf<MEASURE>(material, state, prd, phaseLds);
 
       const int numLights = p.numLights;
-      if ((prd.flags & TWK_FLAG_DIFFUSE) && 0 < numLights)
+      if (p.nextEventEstimation && (prd.flags & TWK_FLAG_DIFFUSE) && 0 < numLights) // closesthit.cu:250-304
       {
+        PhaseScope<MEASURE> phaseSample(phaseLds, SP_NEE_SAMPLE);
         const float sx = rng(prd.seed);
         const float sy = rng(prd.seed);
         const int lightIndex = (1 < numLights) ? min(max(static_cast<int>(floorf(rng(prd.seed) * numLights)), 0), numLights - 1) : 0;
 
         LightSampleD ls;
         sampleLight<ENV>(p, tables, lightIndex, prd.pos, sx, sy, ls);
+        phaseSample.end();
 
         if (0.0f < ls.pdf)
         {
+          PhaseScope<MEASURE> phase(phaseLds, SP_NEE_EVAL);
           const float4 bsdf_pdf = evalBsdf(material, state, prd, ls.direction);
           const V3 bsdf = v3(bsdf_pdf);
           if (0.0f < bsdf_pdf.w && isNotNull(bsdf))
@@ -689,6 +771,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   }
 
   // ---- integrator loop tail, raygeneration.cu:91-146
+  PhaseScope<MEASURE> phaseTail(phaseLds, SP_TAIL);
   if (prd.flags & TWK_FLAG_VOLUME)
   {
     throughput = throughput * exp3(-prd.distance * prd.sigma_t);
@@ -698,6 +781,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   unsigned int albedoWritten = 0u;
   if (p.pathAlbedo != nullptr)
   {
+    PhaseScope<MEASURE> phase(phaseLds, SP_AOV);
     // Denoiser AOVs, Optix7Gui raygeneration.cu:125-164: the albedo of the first diffuse or light event, attenuated by
     // the throughput up to it (after this segment's absorption, before this bounce's BSDF weight); the shading normal
     // of the primary hit in a right-handed camera space.
@@ -733,6 +817,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
     const V3 add = throughput * prd.radiance;
     if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f)
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_RADIANCE);
       float4 r = p.pathRadiance[pixel];
       r.x += add.x; r.y += add.y; r.z += add.z;
       p.pathRadiance[pixel] = r;
@@ -754,6 +839,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   {
     if ((prd.flags & (TWK_FLAG_THINWALLED | TWK_FLAG_TRANSMISSION)) == TWK_FLAG_TRANSMISSION)
     {
+      PhaseScope<MEASURE> phase(phaseLds, SP_VOLUME_PUSH);
       if (prd.flags & TWK_FLAG_FRONTFACE)
       {
         stackIdx = min(stackIdx + 1, TWK_MATERIAL_STACK_LAST);
@@ -911,7 +997,15 @@ TWK_D void accumulateLaunchIndex(const LaunchParams& p, const unsigned int index
     const float4 r = p.pathRadiance[path];
     if (r.w == 0.0f) continue; // launch index outside the image (tile padding): never written, like the early return at raygeneration.cu:180-183
     V3 radiance = v3(r.x, r.y, r.z);
-    if (!(isnan(radiance.x) || isnan(radiance.y) || isnan(radiance.z)))
+    bool keep = !(isnan(radiance.x) || isnan(radiance.y) || isnan(radiance.z));
+    if (p.debugExceptions) // raygeneration.cu:205-218: numerical errors in false colours, and every sample is accumulated
+    {
+      if (!keep)                                                             radiance = v3(1000000.0f, 0.0f, 0.0f); // super red
+      else if (isinf(radiance.x) || isinf(radiance.y) || isinf(radiance.z)) radiance = v3(0.0f, 1000000.0f, 0.0f); // super green
+      else if (radiance.x < 0.0f || radiance.y < 0.0f || radiance.z < 0.0f) radiance = v3(0.0f, 0.0f, 1000000.0f); // super blue
+      keep = true;
+    }
+    if (keep)
     {
       const unsigned int iteration = p.iterationIndex + (unsigned int) s;
       V3 albedo = v3(0.0f), normal = v3(0.0f);

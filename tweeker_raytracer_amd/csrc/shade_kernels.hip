@@ -135,14 +135,24 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 #ifndef TWK_SHADE_WAVES_PRIMARY
 #define TWK_SHADE_WAVES_PRIMARY 4 // the PRIMARY variant carries the ray generation: 13 registers spilled at five waves
 #endif
-// TIME: the time view's build (twk_set_time_view): every path's shading cycles are added to its time word.
-template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool TIME>
+// MEASURE: the measurement build — the time view (twk_set_time_view: every path's shading cycles are added to its time word) and
+// twk_stats_enable (per-phase wave executions, lanes and cycles of shadePath: shade_device.h PhaseScope).
+// TWK_SHADE_EXTRA_FMA=N (experiment builds): N more dependent v_fma_f32 per shaded path — the issue-sensitivity probe of
+// profiles/r05_shade_fma_sensitivity.md.
+#ifndef TWK_SHADE_EXTRA_FMA
+#define TWK_SHADE_EXTRA_FMA 0
+#endif
+template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool MEASURE>
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
   // of iteration i + 1, so no third barrier per iteration is needed.
   __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
   __shared__ unsigned int blockBase[2][2];
+  __shared__ unsigned int phaseWords[MEASURE ? 3 * TWK_SHADE_PHASES : 1];
+  unsigned int* const phaseLds = (MEASURE && p.stats != nullptr) ? phaseWords : nullptr;
+  if (MEASURE) { if (threadIdx.x < 3 * TWK_SHADE_PHASES) phaseWords[threadIdx.x] = 0u; __syncthreads(); }
+  const bool measurePhases = MEASURE && p.stats != nullptr; // time view alone: only the path time
 
   // Instance, material and light records in LDS (scenes whose tables fit): a hit reads ~16 float4 of them, each one divergent
   // lane address for the CU's vector memory path, which takes one per clock — the kernel's bound (rocprofv3: 0.9 lane
@@ -189,17 +199,35 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     ShadeOutput out;
     out.alive = false; out.wantShadow = false;
     const unsigned int pixel = in.pixel;
-    const unsigned int clockBegin = TIME ? (unsigned int) __builtin_readcyclecounter() : 0u;
+    const unsigned int clockBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
+    const unsigned int iterationBegin = clockBegin;
     if (in.inRange && in.rd.w >= 0.0f) // else: beyond the queue, or an inactive launch index (tile column beyond the image)
     {
+      if (measurePhases)
+      {
+        // the wait for the slot's streams, requested one block iteration ahead: their first use
+        PhaseScope<MEASURE> phase(phaseLds, SP_KERNEL_LOAD);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       out.throughputPdf = in.throughputPdf;
       out.seedFlags     = in.seedFlags;
-      shadePath<ENV, TEX, PRIMARY>(p, tables, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
+      if (measurePhases) shadePath<ENV, TEX, PRIMARY, MEASURE>(p, tables, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out, phaseLds);
+      else               shadePath<ENV, TEX, PRIMARY, false>(p, tables, depth, pixel, in.ro, in.rd, in.hit, in.instanceIndex, out);
+#if TWK_SHADE_EXTRA_FMA
+      {
+        float acc = out.throughputPdf.x;
+        const float a = p.sceneEpsilon + 1.0f, b = p.clockScale;
+#pragma unroll
+        for (int k = 0; k < TWK_SHADE_EXTRA_FMA; ++k) acc = __builtin_fmaf(acc, a, b);
+        if (acc == 12345.678f) out.nextPos.x = acc; // keeps the chain alive; never true for finite inputs of this size
+      }
+#endif
       if (p.stats != nullptr) { if (in.instanceIndex < 0) ++statMiss; else ++statHit; }
-      if (TIME) atomicAdd(&p.pathTime[pixel], float((unsigned int) __builtin_readcyclecounter() - clockBegin)); // the shadow ray of this path may be adding its traversal time meanwhile: atomic
+      if (MEASURE && p.pathTime != nullptr) atomicAdd(&p.pathTime[pixel], float((unsigned int) __builtin_readcyclecounter() - clockBegin)); // the shadow ray of this path may be adding its traversal time meanwhile: atomic
     }
     else if (PRIMARY && in.inRange) p.pathRadiance[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // inactive launch index: weight 0, as generateKernel leaves it
 
+    const unsigned int appendBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     const unsigned long long shadowMask = __ballot(out.wantShadow);
     const unsigned long long nextMask   = __ballot(out.alive);
     if (lane == 0)
@@ -249,6 +277,21 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
       p.rayThroughput[qn][n] = out.throughputPdf;
     }
     buffer ^= 1u;
+    if (measurePhases && lane == 0)
+    {
+      // per wave (every wave of the block runs every iteration: the barriers): the append, and the whole iteration
+      const unsigned int now = (unsigned int) __builtin_readcyclecounter();
+      atomicAdd(&phaseWords[SP_KERNEL_APPEND], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_KERNEL_APPEND], (unsigned int) __popcll(shadowMask | nextMask));
+      atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_KERNEL_APPEND], now - appendBegin);
+      atomicAdd(&phaseWords[SP_KERNEL_ITERATION], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_KERNEL_ITERATION], (unsigned int) __popcll(__ballot(in.inRange)));
+      atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_KERNEL_ITERATION], now - iterationBegin);
+    }
+  }
+  if (measurePhases)
+  {
+    __syncthreads();
+    // stats[24 ..): wave executions, lanes, cycles per phase (device_api.hip twk_stats_get)
+    if (threadIdx.x < 3 * TWK_SHADE_PHASES && phaseWords[threadIdx.x] != 0u) atomicAdd(&p.stats[24 + threadIdx.x], (unsigned long long) phaseWords[threadIdx.x]);
   }
 
   if (p.stats != nullptr)
@@ -409,26 +452,27 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);
 }
-template<bool PRIMARY, bool LDS_TABLES, bool TIME>
+template<bool PRIMARY, bool LDS_TABLES, bool MEASURE>
 static void launchShadeVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
   const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
-  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, TIME>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, TIME>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, TIME>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, TIME>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, MEASURE>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 // primary: depth 0 of a pass whose generateKernel was skipped ("primary rays" above)
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream)
 {
-  if (p.pathTime != nullptr) // time view: a diagnostic build, records from the scene's arrays
-  {
-    if (primary) launchShadeVariant<true, false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true>(p, depth, gridBlocks, stream);
-    return;
-  }
   const size_t tableBytes = (size_t) p.numInstances * sizeof(DevInstance) + (size_t) p.numMaterials * sizeof(DevMaterial) + (size_t) p.numLights * sizeof(DevLight);
   const bool lds = TWK_SHADE_LDS_TABLES && tableBytes <= (size_t) TWK_SHADE_TABLE_BYTES;
+  if (p.pathTime != nullptr || p.stats != nullptr) // time view, statistics: the measurement builds
+  {
+    if (primary) { if (lds) launchShadeVariant<true, true, true>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, true>(p, depth, gridBlocks, stream); }
+    else         { if (lds) launchShadeVariant<false, true, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true>(p, depth, gridBlocks, stream); }
+    return;
+  }
   if (primary) { if (lds) launchShadeVariant<true, true, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false>(p, depth, gridBlocks, stream); }
   else         { if (lds) launchShadeVariant<false, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false>(p, depth, gridBlocks, stream); }
 }

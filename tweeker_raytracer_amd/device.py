@@ -121,6 +121,14 @@ class Device:
         """≙ USE_TIME_VIEW: alpha of the accumulation buffer = running mean of the sample's shader-clock cycles x clockFactor x 1e-9."""
         L.check(L.lib.twk_set_time_view(self._h, int(bool(enable))))
 
+    def setNextEventEstimation(self, enable=True):
+        """≙ USE_NEXT_EVENT_ESTIMATION (shaders/config.h:50-52): False = brute-force path tracing without light sampling and MIS weights."""
+        L.check(L.lib.twk_set_next_event_estimation(self._h, int(bool(enable))))
+
+    def setDebugExceptions(self, enable=True):
+        """≙ USE_DEBUG_EXCEPTIONS (raygeneration.cu:205-218): NaN / Inf / negative samples accumulate as super red / green / blue."""
+        L.check(L.lib.twk_set_debug_exceptions(self._h, int(bool(enable))))
+
     def readAov(self, which):
         """Denoiser AOV running means: which = 0 albedo, 1 camera-space normal; float32 [height, launchWidth, 4]."""
         h, w = self.state.resolution[1], self.launchWidth
@@ -219,7 +227,7 @@ class Device:
     def statsGet(self, reset=True):
         s = L.LaunchStats()
         L.check(L.lib.twk_stats_get(self._h, C.byref(s), int(bool(reset))))
-        return {name: (list(getattr(s, name)) if name == "waveCycles" else getattr(s, name)) for name, _ in L.LaunchStats._fields_}
+        return {name: (list(getattr(s, name)) if name in ("waveCycles", "shadePhaseWaveSteps", "shadePhaseLanes", "shadePhaseCycles") else getattr(s, name)) for name, _ in L.LaunchStats._fields_}
 
     def streamPeakGBps(self, nbytes=1 << 30, repeats=10):
         g = C.c_float(0)
