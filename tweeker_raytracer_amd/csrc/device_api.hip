@@ -138,7 +138,6 @@ struct TwkDevice_t
   unsigned long long* d_stats = nullptr;
   unsigned int* h_dropped = nullptr; unsigned int* d_dropped = nullptr; // pinned + device-mapped: LaunchParams::droppedPushes
   int* d_spill = nullptr; size_t spillLanes = 0;
-  float4* d_raySetup = nullptr; size_t raySetupPaths = 0; // experiment builds only (TWK_EXPERIMENT_PRESETUP)
   bool packedQueue = true; // TWK_PACKED_QUEUE=0: A/B
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
   // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
@@ -302,10 +301,6 @@ static void refreshParams(TwkDevice dev)
   p.traceStackSpill = dev->d_spill;
   p.droppedPushes = dev->d_dropped;
   p.packedQueue = 0; // renderPass decides per pass
-  p.raySetup = nullptr;
-#if TWK_EXPERIMENT_PRESETUP
-  p.raySetup = dev->d_raySetup;
-#endif
 }
 
 static int traceGridBlocks(TwkDevice dev) { return dev->numCUs * TWK_TRACE_WAVES7; } // the larger of the two persistent grids (sizes the spill stacks); a launch uses numCUs x params.traceWaves
@@ -387,14 +382,6 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     dev->spillLanes = lanes;
   }
 
-#if TWK_EXPERIMENT_PRESETUP
-  if ((size_t) dev->allocatedPaths > dev->raySetupPaths)
-  {
-    freeDevice(dev->d_raySetup);
-    HIP_TRY(hipMalloc(&dev->d_raySetup, sizeof(float4) * 4 * (size_t) dev->allocatedPaths)); // two float4 per slot, a closest-hit and a shadow slot per path
-    dev->raySetupPaths = (size_t) dev->allocatedPaths;
-  }
-#endif
   // carve the block
   LaunchParams& p = dev->params;
   const size_t n = (size_t) dev->allocatedPaths;
@@ -587,7 +574,6 @@ static LaunchParams laneParams(TwkDevice dev, const LaunchParams& p, int lane, i
   if (q.pathTime) q.pathTime += base;
   q.counters = dev->d_counters + (size_t) lane * TWK_COUNTER_WORDS;
   q.traceStackSpill = dev->d_spill + (size_t) lane * traceBlocks * TWK_TRACE_BLOCK * TWK_TRACE_STACK_SPILL;
-  if (q.raySetup) q.raySetup += 4 * base; // experiment builds: two float4 per slot, two slots per path
   return q;
 }
 
@@ -806,7 +792,7 @@ try
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
   freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes); freeDevice(dev->d_topNodes7); freeDevice(dev->d_tileEntries);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
-  freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill); freeDevice(dev->d_pathTime); freeDevice(dev->d_raySetup);
+  freeDevice(dev->d_counters); freeDevice(dev->d_stats); freeDevice(dev->d_spill); freeDevice(dev->d_pathTime);
   if (dev->h_dropped) { (void) hipHostFree(dev->h_dropped); dev->h_dropped = nullptr; dev->d_dropped = nullptr; }
   freeDevice(dev->d_firstHit); freeDevice(dev->d_firstHitInstance);
   freeDevice(dev->d_pathAlbedo); freeDevice(dev->d_pathNormal); freeDevice(dev->d_aovAlbedo); freeDevice(dev->d_aovNormal);

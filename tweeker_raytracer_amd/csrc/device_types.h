@@ -249,9 +249,6 @@ struct LaunchParams
   // TWK_ENTRY_TILE launch indices two int4 = (count, ref 0..6): the subtrees a ray through that tile can reach, nearest first.
   const int4* tileEntries;
   int     tilesX;
-  // Experiment builds only (-DTWK_EXPERIMENT_PRESETUP=1, tools/experiments/): two float4 per queue slot of the traversal launch —
-  // (1 / d guarded, Woop permutation bits) and (Sx, Sy, Sz, 0) — written by raySetupKernel in front of it; nullptr otherwise.
-  float4* raySetup;
   // 1: the queues shadeKernel writes (every depth >= 1) carry launch index + path flags in the .w of the origin and the LCG state in
   // the .w of the direction — the tmin / tmax of a continuation ray are the constants sceneEpsilon / RT_DEFAULT_MAX — and the
   // rayPixel / raySeedFlags streams are neither written nor read: 12 bytes less per path and bounce on both sides (TWK_PACKED_*).

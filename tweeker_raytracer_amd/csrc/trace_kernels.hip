@@ -43,32 +43,9 @@ static void launchTraceOpaque(const LaunchParams& p, int depth, int gridBlocks, 
 // primary: depth 0 of a pass whose generateKernel was skipped.
 void launchTrace8(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream); // trace_kernels8.hip
 
-#if TWK_EXPERIMENT_PRESETUP
-// Experiment: the per-ray constants of the traversal (trace_device.h setupRay / woopSetup — the same functions, so the same
-// bits) for every slot of trace launch `depth`, one thread per slot, in front of the launch.
-__global__ void __launch_bounds__(256) raySetupKernel(LaunchParams p, int depth)
-{
-  const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
-  const unsigned int numShadow  = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + 1] : 0u;
-  const unsigned int total = numClosest + numShadow;
-  const int q = depth & 1;
-  for (unsigned int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x)
-  {
-    const float4 d = (slot < numClosest) ? p.rayDir[q][slot] : p.shadowDir[slot - numClosest];
-    TraceRay ray; WoopConstants woop;
-    setupRay(ray, v3(0.0f), v3(d));
-    woopSetup(v3(d), woop);
-    p.raySetup[2 * (size_t) slot]     = make_float4(ray.id.x, ray.id.y, ray.id.z, __uint_as_float(woop.perm));
-    p.raySetup[2 * (size_t) slot + 1] = make_float4(woop.Sx, woop.Sy, woop.Sz, 0.0f);
-  }
-}
-#endif
 
 void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream)
 {
-#if TWK_EXPERIMENT_PRESETUP
-  if (!primary && p.raySetup != nullptr) hipLaunchKernelGGL(raySetupKernel, dim3(256 * 16), dim3(256), 0, stream, p, depth);
-#endif
   if (p.wide8 != nullptr && !p.twoLevel) { launchTrace8(p, depth, count, primary, gridBlocks, stream); return; } // the builds over the compressed 8-ary nodes
   if (!p.hasCutout)
   {

@@ -70,9 +70,6 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 //     slowest lane (measured: 10.5 of 64 lanes active per VALU instruction);
 //   * "while-while": all lanes first descend inner nodes together, then handle their leaf / instance entry /
 //     instance exit once, so a wave does not pay for three code paths per step.
-#ifndef TWK_TRACE_DEFER_RESULTS
-#define TWK_TRACE_DEFER_RESULTS 1
-#endif
 #ifndef TWK_TRACE_REFILL
 #define TWK_TRACE_REFILL 52
 #endif
@@ -206,12 +203,11 @@ traceKernel(LaunchParams p, int depth)
 
   for (;;)
   {
-#if TWK_TRACE_DEFER_RESULTS
     // ---- the results of the rays that completed since the last refill ----------------------------
     // Written HERE, once per pass of the outer loop, not in the round a ray completes in: a lane that has finished its ray takes
     // no new one before the next refill anyway, so it loses nothing by waiting — and the wave runs this code (two stores; for a
     // shadow ray two dependent fetches and a read-modify-write of the path's radiance) once with every finished lane active
-    // instead of in nearly every round with one to three (round 4; `TWK_TRACE_DEFER_RESULTS=0` restores the per-round form).
+    // instead of in nearly every round with one to three (round 4).
     if (state & ST_DONE)
     {
       state &= ~ST_DONE;
@@ -285,7 +281,6 @@ traceKernel(LaunchParams p, int depth)
       }
     }
 
-#endif
     // ---- refill idle lanes from the wave's pool ------------------------------------------------------
     // The wave waits here for the ray records it fetches; the other waves of the SIMD cover that wait (prefetch variants that
     // were built and measured: DESIGN.md 4.1 "ray prefetch").
@@ -340,22 +335,8 @@ traceKernel(LaunchParams p, int depth)
             else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT); }
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
-#if TWK_EXPERIMENT_PRESETUP
-            // experiment: what the refill computes per ray — three guarded reciprocals, the Woop
-            // permutation and its three IEEE divisions — comes from a stream a full-occupancy kernel wrote in front of this launch
-            if (!PRIMARY && p.raySetup != nullptr)
-            {
-              const float4 sa = p.raySetup[2 * (size_t) slot], sb = p.raySetup[2 * (size_t) slot + 1];
-              ray.o = org; ray.d = dir; ray.id = v3(sa.x, sa.y, sa.z);
-              ray.ood = v3(org.x * ray.id.x, org.y * ray.id.y, org.z * ray.id.z);
-              woop.perm = __float_as_uint(sa.w); woop.Sx = sb.x; woop.Sy = sb.y; woop.Sz = sb.z;
-            }
-            else
-#endif
-            {
             setupRay(ray, org, dir);
             woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
-            }
             currentInstance = -1; sp = 0; guard = 0;
             if (WIDE8)
             {
@@ -683,82 +664,6 @@ traceKernel(LaunchParams p, int depth)
         if (node == TWK_BVH_SENTINEL) state = (state & ~ST_HAS_RAY) | ST_DONE;
       }
 
-#if !TWK_TRACE_DEFER_RESULTS
-      // write the result of rays that completed in this round
-      if (state & ST_DONE)
-      {
-        state &= ~ST_DONE;
-        const bool isShadow = (state & ST_SHADOW) != 0u;
-        if (state & ST_RETRACE)
-        {
-          // LDS stack overflow: hand the ray to traceOverflowKernel (spilling single-ray traversal), which runs
-          // right behind this launch; nothing is written for it here.
-          state = (state & ~ST_RETRACE) | ST_OVERFLOWED;
-          const unsigned int k = atomicAdd(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3], 1u);
-          p.overflowSlots[k] = slot;
-          if (PRIMARY && CUTOUT) p.hitRecord[slot] = make_float4(tmin, 0.0f, 0.0f, 0.0f); // where the re-trace continues: behind the candidates ignored so far
-        }
-        if (COUNT) maxSteps = max(maxSteps, guard);
-        const bool ignoredCandidate = CUTOUT && !(state & ST_OVERFLOWED) && res.instance >= 0 &&
-                                      cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY);
-        if (ignoredCandidate)
-        {
-          // continue strictly behind the ignored candidate: the traversal starts again with tmin = its distance. The ray comes from
-          // its record again (PRIMARY: is computed again) — kept in registers for this, origin and direction cost the cutout builds
-          // 14 VGPRs and their sixth block per CU (rounds 2-3: 93-95 VGPRs, five blocks; round 4: 79, six).
-          tmin = res.t;
-          float4 o, d;
-          if (PRIMARY)
-          {
-            const PrimaryRay pr = primaryRay(p, slot);
-            o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, 0.0f);
-            d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, RT_DEFAULT_MAX);
-          }
-          else
-          {
-            o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
-            d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
-          }
-          org = v3(o); dir = v3(d);
-          res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
-          setupRay(ray, org, dir);
-          woopSetup(dir, woop);
-          currentInstance = -1; sp = 0; node = WIDE8 ? 0 : p.topRoot; guard = 0;
-          if (!WIDE8 && p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; }
-          state |= ST_HAS_RAY;
-        }
-        else if (state & ST_OVERFLOWED) { state &= ~ST_OVERFLOWED; }
-        else if (!isShadow)
-        {
-          p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
-          p.hitInstance[slot] = res.instance;
-          if (COUNT) ++closestCount;
-          if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : (packed ? (__float_as_uint(p.rayOrg[q][slot].w) & TWK_PACKED_PIXEL_MASK) : p.rayPixel[q][slot])], float((unsigned int) __builtin_readcyclecounter() - rayClock)); // time view: the lane's cycles from taking the ray to its result
-          if (p.firstHit != nullptr && depth == 0)
-          {
-            const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
-            p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
-            p.firstHitInstance[pixel] = res.instance;
-          }
-        }
-        else
-        {
-          if (COUNT) ++shadowCount;
-          if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[p.shadowPixel[slot - numClosest]], float((unsigned int) __builtin_readcyclecounter() - rayClock));
-          if (res.instance < 0)
-          {
-            // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)
-            const unsigned int s = slot - numClosest;
-            const unsigned int pixel = p.shadowPixel[s];
-            const float4 c = p.shadowPending[s];
-            float4 r = p.pathRadiance[pixel];
-            r.x += c.x; r.y += c.y; r.z += c.z;
-            p.pathRadiance[pixel] = r;
-          }
-        }
-      }
-
-#endif
       TWK_PHASE_END(4)
       if (!(state & ST_HAS_RAY)) node = TWK_BVH_SENTINEL; // what the node loop's condition relies on
       const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
