@@ -149,7 +149,7 @@ typedef struct TwkLaunchStats
   uint64_t shadedHits;
   uint64_t missed;
   uint64_t maxNodesPerRay;  /* longest single traversal (inner-node visits) seen by the wavefront trace kernel */
-  uint64_t tailRays;        /* rays (both kinds) traced inside the tail kernel; not included in the fields above */
+  uint64_t tailRays;        /* reserved (0): the persistent tail kernel of rounds 1-4 is an experiment patch now (tools/experiments/) */
   uint64_t tailNodesVisited;
   uint64_t tailTrianglesTested;
   uint64_t tailInstancesEntered;
@@ -201,7 +201,7 @@ enum
   TWK_KERNEL_TRACE    = 1,
   TWK_KERNEL_SHADE    = 2,
   TWK_KERNEL_ACCUM    = 3,
-  TWK_KERNEL_TAIL     = 4,  /* deep bounces in one persistent kernel (trace + shade per lane) */
+  TWK_KERNEL_TAIL     = 4,  /* reserved: never launched by this build */
   TWK_KERNEL_COUNT    = 5
 };
 

@@ -293,25 +293,6 @@ def test_fewer_materials_or_lights_than_the_built_scene_uses_is_refused(twk):
     dev.close()
 
 
-def test_tail_kernel_option_does_not_change_the_image(twk, monkeypatch):
-    """TWK_TAIL_DEPTH=n (off by default): bounces >= n of every surviving path run in one persistent kernel
-    instead of per-depth launches. Same device functions, same bits."""
-    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (160, 90))
-    imgs = []
-    for tail in (None, "2", "5"):
-        if tail is None:
-            monkeypatch.delenv("TWK_TAIL_DEPTH", raising=False)
-        else:
-            monkeypatch.setenv("TWK_TAIL_DEPTH", tail)
-        dev = twk.Device(ordinal=0, miss=app.info.miss)
-        app.initDevice(dev)
-        for it in range(3):
-            dev.render(it)
-        imgs.append(dev.getOutputBufferHost())
-        dev.close()
-    assert np.array_equal(_bits(imgs[0]), _bits(imgs[1])) and np.array_equal(_bits(imgs[0]), _bits(imgs[2]))
-
-
 def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
     """A pass whose path streams exceed the memory it may take (here a 6 MiB budget: the real limit is the device's
     HBM) is cut in halves until it fits; the image is the one of the undivided pass, and a frame that does not fit

@@ -27,7 +27,6 @@ namespace twk {
 void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream);
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream);
 void launchGenerate(const LaunchParams& p, hipStream_t stream);
-void launchTail(const LaunchParams& p, int depth0, bool count, int gridBlocks, hipStream_t stream);
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream);
 hipError_t buildWide8(hipStream_t stream, const BvhNode* nodes, int numBinaryNodes, int root, int numTriangles, float4** outNodes, int* outCount, int** outSlotMap, int* outLevels);
 void launchPermuteSlots(const int* slotMap, int count, const float4* triangles, const float4* shade, float4* outTriangles, float4* outShade, hipStream_t stream);
@@ -152,7 +151,6 @@ struct TwkDevice_t
   std::vector<TimedLaunch> timed; size_t timedUsed = 0;
   float profileMs[TWK_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int   profileLaunches[TWK_KERNEL_COUNT] = {0, 0, 0, 0, 0};
-  int   tailDepth = 0; // > 0: bounces >= tailDepth run in the tail kernel (TWK_TAIL_DEPTH); measured no faster than the wavefront at 1920x1080, kept off
   // Deferred launches: twk_launch only records the iteration; consecutive iterations are rendered together as one
   // wavefront pass of up to batchMax samples per pixel when the batch is full or anything observes the device.
   int   batchMax = 64;
@@ -544,7 +542,7 @@ static int chooseLanes(TwkDevice dev, int numPaths)
   int lanes = 1;
   if (dev->lanesForced > 0) lanes = dev->lanesForced;
   else if (numPaths <= TWK_LANES2_MAX_PATHS) lanes = 2;
-  if (dev->captureFirstHits || dev->tailDepth > 0) lanes = 1; // debug capture indexes by launch index; the tail kernel owns the whole grid
+  if (dev->captureFirstHits) lanes = 1; // debug capture indexes by launch index
   // twk_profile_enable: the per-kind sums of twk_profile_get are sums of launch durations; the launches of two lanes overlap
   // in time, so their sum would be about twice the wall time of the kind. A profiled pass runs as ONE lane.
   if (dev->profileEnabled) lanes = 1;
@@ -588,7 +586,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   p.pathBase = 0;
 
   // launch index + path flags and the LCG state in the constant words of the queued rays (device_types.h LaunchParams::packedQueue)
-  p.packedQueue = (dev->packedQueue && !p.hasCutout && dev->tailDepth == 0 && (unsigned int) p.numPaths <= TWK_PACKED_PIXEL_MASK) ? 1 : 0;
+  p.packedQueue = (dev->packedQueue && !p.hasCutout && (unsigned int) p.numPaths <= TWK_PACKED_PIXEL_MASK) ? 1 : 0;
   const int maxDepth = dev->state.pathLengths[1];
   const int lanes = chooseLanes(dev, p.numPaths);
   // every block of every lane's persistent trace kernel resident at once: the lanes share the CUs' block slots
@@ -596,10 +594,9 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   if (lanes > 1 && dev->laneTraceWaves > 0) traceWaves = std::min(dev->laneTraceWaves, 2 * TWK_TRACE_WAVES / lanes); // TWK_LANE_TRACE_WAVES (experiments; the spill stacks hold two full grids)
   const int traceGrid = dev->numCUs * traceWaves;
 
-  // Bounces [0, wavefrontDepth) run as per-depth trace/shade launches over compacted queues; the remaining bounces
-  // of every surviving path run inside one persistent tail kernel (tail_kernel.hip).
-  int wavefrontDepth = maxDepth;
-  if (dev->tailDepth > 0 && dev->tailDepth < maxDepth) wavefrontDepth = dev->tailDepth;
+  // Every bounce runs as a per-depth trace / shade launch pair over compacted queues (the persistent tail kernel for the deep
+  // bounces, rounds 1-4, lives in tools/experiments/r04_tail_kernel.patch: no faster at any launch size measured).
+  const int wavefrontDepth = maxDepth;
 
   // Primary rays are computed by the first traversal and the first shade launch instead of being written by generateKernel and
   // read back (shade_kernels.hip "primary rays") — unless the paths have no bounce to be shaded in.
@@ -688,10 +685,6 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
     // closest hits of queue `wavefrontDepth` (empty when wavefrontDepth == maxDepth) + the shadow rays of the last shade
     for (int k = 0; k < active; ++k) { timedLaunchBegin(dev, TWK_KERNEL_TRACE, laneS[k]); launchTrace(laneP[k], wavefrontDepth, dev->statsEnabled || dev->timeView, false, traceGrid, laneS[k]); timedLaunchEnd(dev, laneS[k]); }
   }
-  if (wavefrontDepth < maxDepth)
-  {
-    timedLaunchBegin(dev, TWK_KERNEL_TAIL, laneS[0]); launchTail(laneP[0], wavefrontDepth, dev->statsEnabled, dev->numCUs * 3, laneS[0]); timedLaunchEnd(dev, laneS[0]);
-  }
   for (int k = 0; k < active; ++k)
   {
     if (laneS[k] == dev->stream) continue;
@@ -757,7 +750,6 @@ try
     return twkSetError(TWK_ERROR_NO_DEVICE, std::string("twk_device_create: ") + hipGetErrorString(err));
   }
   dev->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* e = getenv("TWK_TAIL_DEPTH")) dev->tailDepth = atoi(e);
   if (const char* e = getenv("TWK_PASS_LANES")) dev->lanesForced = std::max(0, std::min(TWK_MAX_LANES, atoi(e)));
   if (const char* e = getenv("TWK_LANE_TRACE_WAVES")) dev->laneTraceWaves = std::max(0, atoi(e));
   if (const char* e = getenv("TWK_TOP_CACHE")) dev->topCache = (atoi(e) != 0);
@@ -1291,7 +1283,6 @@ try
   {
     if (m.textureAlbedo && dev->d_texels[TWK_TEXTURE_ALBEDO] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: a material uses the albedo texture but none was uploaded");
     if (m.textureCutout && dev->d_texels[TWK_TEXTURE_CUTOUT] == nullptr) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: a material uses the cutout texture but none was uploaded");
-    if (m.textureCutout && dev->tailDepth > 0) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_launch: the tail kernel (TWK_TAIL_DEPTH) does not implement cutout opacity");
   }
 
   // Asynchronous like optixLaunch: the iteration is recorded; consecutive iterations are rendered together (up to
@@ -1379,7 +1370,6 @@ try
   int rc = activate(dev, "twk_enable_aov"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
   dev->aovEnabled = (enable != 0);
-  if (dev->aovEnabled && dev->tailDepth > 0) { dev->aovEnabled = false; return twkSetError(TWK_ERROR_INVALID_STATE, "twk_enable_aov: not available together with the tail kernel (TWK_TAIL_DEPTH)"); }
   return TWK_SUCCESS;
 }
 TWK_CATCH("twk_enable_aov")
@@ -1389,7 +1379,6 @@ try
 {
   int rc = activate(dev, "twk_set_time_view"); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  if (enable && dev->tailDepth > 0) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_set_time_view: not available together with the tail kernel (TWK_TAIL_DEPTH)");
   dev->timeView = (enable != 0);
   return TWK_SUCCESS;
 }
@@ -1559,7 +1548,7 @@ try
   HIP_TRY(hipMemcpy(h, dev->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   stats->radianceRays = h[0]; stats->shadowRays = h[1]; stats->nodesVisited = h[2]; stats->trianglesTested = h[3];
   stats->instancesEntered = h[4]; stats->shadedHits = h[5]; stats->missed = h[6]; stats->maxNodesPerRay = h[7];
-  stats->tailRays = h[8]; stats->tailNodesVisited = h[9]; stats->tailTrianglesTested = h[10]; stats->tailInstancesEntered = h[11]; stats->overflowRays = h[12];
+  stats->overflowRays = h[12]; // tailRays .. tailInstancesEntered (words 8-11): the tail kernel is not part of this build, they stay 0
   stats->nodeWaveSteps = h[13]; stats->triangleWaveSteps = h[14]; stats->leafWaveSteps = h[15];
   stats->cachedNodesVisited = h[16]; stats->droppedStackPushes = dev->h_dropped ? *dev->h_dropped : 0u;
   for (int i = 0; i < 6; ++i) stats->waveCycles[i] = h[18 + i];

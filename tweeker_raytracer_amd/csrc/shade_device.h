@@ -1,4 +1,4 @@
-// Device functions of the shading stage, shared by shade_kernels.hip and tail_kernel.hip.
+// Device functions of the shading stage (shade_kernels.hip; trace_persistent.h takes tex2D / rng / tea from here).
 //
 // Reference programs restated (apps/rtigo3/shaders/): tea/rng random_number_generators.h:40-78, the BSDF callables
 // bxdf_diffuse.cu / bxdf_specular.cu / bxdf_ggx_smith.cu, light sampling light_sample.cu, miss programs miss.cu:41-109,
@@ -513,7 +513,7 @@ TWK_D unsigned int waveAppend(unsigned int* counter)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Shading of one path segment, shared by shadeKernel (wavefront bounces) and tailKernel (deep bounces):
+// Shading of one path segment (shadeKernel; the host build of the kernels, oracle/host_kernels.cpp):
 // miss or closest-hit shading, next-event estimation, then the integrator's loop tail. Throughput, pdf, RNG state
 // and flags come in and go out through `out` (they travel in the ray queue); radiance and the volume stack are
 // per-path arrays; the continuation ray and the shadow ray are returned in registers.
@@ -863,7 +863,7 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
   out.nextPos = prd.pos; out.nextDir = prd.wi;
 }
 
-// The same with the records read from the scene's arrays (tail kernel, host build of the kernels).
+// The same with the records read from the scene's arrays (host build of the kernels).
 template<bool ENV = true, bool TEX = true, bool PRIMARY = false>
 TWK_D void shadePath(const LaunchParams& p, int depth, unsigned int pixel, const float4& ro, const float4& rd,
                      const float4& hit, int instanceIndex, ShadeOutput& out)

@@ -1,4 +1,4 @@
-// Device functions of ray traversal, shared by trace_kernels.hip and tail_kernel.hip: conservative slab test,
+// Device functions of ray traversal, shared by the traversal kernels (trace_persistent.h, trace_kernels.hip) and the host build of the kernels: conservative slab test,
 // watertight triangle test (Woop, Benthin, Wald, JCGT 2013), and the single-ray two-level traversal whose stack
 // continues from LDS into HBM. See trace_kernels.hip for the contract these stand in for (optixTrace).
 #pragma once
