@@ -33,7 +33,6 @@ HBM_SPEC_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; the denomina
 
 # Algorithmic bytes of the traversal kernel, SURVEY.md §8(d)'s record table (cache hits do not reduce them):
 B_RAY_FIXED = 48      # 32 B ray record in + 16 B hit record out (shadow rays: 32 B ray + 16 B pending contribution)
-B_NODE8, L_NODE8 = 80, 5  # one compressed 8-ary node visit (csrc/device_types.h): 80 bytes, five 16-byte lane loads
 B_NODE = 64           # one 4-ary wide-node visit: two levels of the binary tree in ONE 64-byte quantised record (device_types.h), the size of §8(d)'s binary node
 B_TRIANGLE = 48       # one Woop triangle slot (three float4)
 B_INSTANCE = 64       # instance entry (two-level scenes only): world-to-object rows + BVH root, what an IAS leaf hands an OptiX traversal
@@ -336,8 +335,8 @@ def main():
         gather_peak = dev.gatherPeak(32 << 20)              # G lane-loads/s (16 B each) from a scene-sized, cache-resident table
         rays = st["radianceRays"] + st["shadowRays"]
         bi = dev.buildInfo()
-        wide8 = int(bi["wide8Nodes"]) > 0                   # the persistent kernel walks the compressed 8-ary nodes (80 B, five lane loads per visit)
-        b_node, l_node = (B_NODE8, L_NODE8) if wide8 else (B_NODE, L_NODE)
+        has_cutout = any(bool(m.useCutoutTexture) for m in app.materials)  # the CUTOUT builds of the traversal kernel run the any-hit candidate loop
+        b_node, l_node = B_NODE, L_NODE
         algo_bytes = B_RAY_FIXED * rays + b_node * st["nodesVisited"] + B_TRIANGLE * st["trianglesTested"] + B_INSTANCE * st["instancesEntered"]
         memory_nodes = st["nodesVisited"] - st["cachedNodesVisited"]  # the top of the tree is served from LDS (TWK_NODE_CACHED)
         lane_loads = L_RAY * rays + l_node * memory_nodes + L_TRIANGLE * st["trianglesTested"] + L_INSTANCE * st["instancesEntered"]
@@ -349,16 +348,16 @@ def main():
         pmc, pmc_source = (None, "N > 1") if n_gpus != 1 else pick_pmc_record(args.steps, result["config"]["batch_depth"], (width, height), args.sphere_tess)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         hbm_side_gbps = (traffic / avg_launch_s / 1.0e9) if traffic else None
-        scene_bytes = (int(bi["wide8Nodes"]) * 80 if wide8 else int(bi["nodes"]) * 64) + int(bi["triangleSlots"]) * 48  # what the traversal kernel reads of the scene: its nodes + triangle slots
+        scene_bytes = int(bi["nodes"]) * 64 + int(bi["triangleSlots"]) * 48  # what the traversal kernel reads of the scene: its nodes + triangle slots
         cache_resident = scene_bytes < (256 << 20)                           # MI355X_MICROARCH: Infinity Cache 256 MiB (L2 32 MiB aggregate)
         algo_frac_spec = algo_gbps / HBM_SPEC_GBPS
         # SURVEY 8(d) / task contract: achieved = ALGORITHMIC bytes per launch / average launch duration of the dominant kernel,
         # peak = HBM spec. On a scene that lives in the caches these bytes are served by LDS / L1 / L2, so `frac` can pass 1:
         # it then says "not HBM-bound", nothing more. What does bound the kernel, and the HBM-side bytes, are stated beside it.
         result["roofline"] = {
-            "kernel": "twk::traceKernel<false, false, %s, %s, false, %s>" % ("true" if st["instancesEntered"] else "false", "true" if bi["traceBlocksPerCU"] == 7 else "false", "true" if wide8 else "false"),
-            "kernel_note": "template arguments: COUNT, CUTOUT, TWO_LEVEL, W7 (seven resident blocks per CU), PRIMARY, WIDE8 (compressed 8-ary nodes); the first of a pass's launches is the <.., true, ..> PRIMARY build, which computes the primary rays instead of fetching them",
-            "node_width": 8 if wide8 else 4,
+            "kernel": "twk::traceKernel<false, %s, %s, %s, false>" % ("true" if has_cutout else "false", "true" if st["instancesEntered"] else "false", "true" if bi["traceBlocksPerCU"] == 7 else "false"),
+            "kernel_note": "template arguments: COUNT, CUTOUT, TWO_LEVEL, W7 (seven resident blocks per CU), PRIMARY; the first of a pass's launches is the <.., true> PRIMARY build, which computes the primary rays instead of fetching them",
+            "node_width": 4,
             "trace_blocks_per_cu": int(bi["traceBlocksPerCU"]),
             # what binds the kernel (VERDICT / ADVICE round 3): on a scene the caches hold it is not HBM — `frac` below stays the
             # contract's algorithmic-bytes fraction and may exceed 1 there (frac_valid says so); frac_of_binding_limit is the
@@ -371,7 +370,7 @@ def main():
             "peak": HBM_SPEC_GBPS,
             "unit": "GB/s",
             "frac": algo_frac_spec,
-            "frac_definition": "SURVEY 8(d) algorithmic bytes (48 B per ray + 64 B per 4-ary / 80 B per 8-ary node visit + 48 B per triangle test + 64 B per instance entry, cache hits NOT deducted) / average launch duration of this kernel (hipEvents on the handle's stream, this run) / 8 TB/s HBM spec",
+            "frac_definition": "SURVEY 8(d) algorithmic bytes (48 B per ray + 64 B per 4-ary node visit + 48 B per triangle test + 64 B per instance entry, cache hits NOT deducted) / average launch duration of this kernel (hipEvents on the handle's stream, this run) / 8 TB/s HBM spec",
             "traffic": traffic,
             "traffic_source": (f"{pmc_source}: rocprofv3 --pmc passes of this command line (FETCH_SIZE x 2 + WRITE_SIZE per launch of this kernel, tools/pmc_collect.sh, tools/pmc_traffic.py), same steps / batch / resolution; carried, not measured in this run"
                                if pmc else f"null: {pmc_source}"),
@@ -414,7 +413,7 @@ def main():
             "stream_peak_gbps_measured": stream_peak,
             "hbm_spec_gbps": HBM_SPEC_GBPS,
             "algorithmic_bytes_per_launch": algo_bytes / trace_launches,
-            "algorithmic_record_table": {"ray_in_hit_out": B_RAY_FIXED, ("node_visit(compressed 8-ary node)" if wide8 else "wide_node_visit(quantised 4-ary node, two binary levels)"): b_node, "triangle": B_TRIANGLE, "instance_entry": B_INSTANCE},
+            "algorithmic_record_table": {"ray_in_hit_out": B_RAY_FIXED, "wide_node_visit(quantised 4-ary node, two binary levels)": b_node, "triangle": B_TRIANGLE, "instance_entry": B_INSTANCE},
             "avg_launch_ms": trace_ms / trace_launches,
             "launches": trace_launches,
             "rays_per_step": rays / args.steps,

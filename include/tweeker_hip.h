@@ -261,9 +261,9 @@ typedef struct TwkBuildInfo
   uint64_t triangleSlots, nodes, instances, flattenedInstances;
   uint64_t maxTraversalDepth; /* ABI 4: binary-tree levels of the deepest root-to-leaf path (top level + the deepest tree below it); twk_build refuses a scene deeper than the traversal stacks */
   uint64_t directLeafInstances; /* ABI 5: flattened instances of at most a leaf's triangles that ARE leaves of the top level (no tree of their own is visited) */
-  uint64_t traceBlocksPerCU;    /* ABI 5: resident blocks per CU of the persistent traversal kernel for this scene with the materials as they are now: 6, or 7 (flattened, no cutout opacity, at most 1 M nodes) */
-  uint64_t wide8Nodes;          /* ABI 8: compressed 8-ary nodes the persistent kernel walks instead of the 4-ary ones (csrc/bvh_wide8.hip; flattened scenes), 0: none were built */
-  uint64_t wide8Levels;         /* ABI 8: depth of that 8-ary tree */
+  uint64_t traceBlocksPerCU;    /* ABI 5: resident blocks per CU of the persistent traversal kernel for this scene with the materials as they are now: 7 (every instance flattened, at most 1 M nodes — with or without cutout opacity), 5 (two-level with cutout opacity), else 6 */
+  uint64_t wide8Nodes;          /* ABI 8: reserved, 0 — the compressed 8-ary nodes of round 4 lost on every scene and are an experiment patch now (tools/experiments/r04_wide8_nodes.patch) */
+  uint64_t wide8Levels;         /* ABI 8: reserved, 0 */
 } TwkBuildInfo;
 int twk_get_build_info(TwkDevice dev, TwkBuildInfo* info);
 

@@ -246,11 +246,9 @@ def walk_same_bvh(acceleration, rays, anyHit=False):
     tbg = np.zeros((n, 3), np.float32)
     ids = np.zeros((n, 2), np.int32)
     counts = (C.c_uint64 * 4)()
-    if int(info.get("nodeFloats", 16)) == 20:  # the compressed 8-ary nodes (flattened scene, root = node 0)
-        rc = lib.orc_walk_same_bvh8(_f(nodes), _f(tris), _f(rays), C.c_uint64(n), int(bool(anyHit)), _f(tbg), ids.ctypes.data_as(_ip), counts)
-    else:
-        rc = lib.orc_walk_same_bvh(_f(nodes), int(info["root"]), int(info.get("root2", -1)), _f(tris), _f(inst), _f(rays), C.c_uint64(n), int(bool(anyHit)),
-                                   _f(tbg), ids.ctypes.data_as(_ip), counts)
+    assert int(info.get("nodeFloats", 16)) == 16
+    rc = lib.orc_walk_same_bvh(_f(nodes), int(info["root"]), int(info.get("root2", -1)), _f(tris), _f(inst), _f(rays), C.c_uint64(n), int(bool(anyHit)),
+                               _f(tbg), ids.ctypes.data_as(_ip), counts)
     assert rc == 0
     return tbg, ids, {"nodesVisited": counts[0], "trianglesTested": counts[1], "instancesEntered": counts[2], "deepestStack": counts[3]}
 

@@ -205,113 +205,5 @@ int orc_walk_same_bvh(const float* wideNodes, int root, int root2, const float* 
   return 0;
 }
 
-// The same for the compressed 8-ary nodes (tweeker_raytracer_amd/csrc/device_types.h "compressed 8-ary node", the WIDE8 builds of
-// the persistent kernel in trace_persistent.h), 20 floats per node, root = node 0, flattened scenes only: the hit masks of a
-// node's children in slot order, the inner hits permuted into traversal order (bit p = slot p ^ octant) by three conditional
-// swaps, ONE (childBase, mask) stack entry per node, the nearest child by find-first-bit, and the triangles of the node's leaf
-// children tested BEFORE the chosen inner child is entered (it is chosen first, exactly as the kernel does).
-// counts: [0] nodes visited, [1] triangles tested, [2] 0, [3] deepest stack (entries).
-int orc_walk_same_bvh8(const float* nodes8, const float* triangles, const float* rays, uint64_t numRays, int anyHit,
-                       float* tBetaGamma, int* ids, uint64_t counts[4])
-{
-  counts[0] = counts[1] = counts[2] = counts[3] = 0;
-  std::vector<int> stackBase(4096); std::vector<unsigned int> stackBits(4096);
-  for (uint64_t i = 0; i < numRays; ++i)
-  {
-    const float* r = rays + 8 * i;
-    const V3 org = v3(r[0], r[1], r[2]), dir = v3(r[4], r[5], r[6]);
-    const float tmin = r[3];
-    float bestT = r[7], bestBeta = 0.0f, bestGamma = 0.0f;
-    int bestInstance = -1, bestPrimitive = -1;
-    Ray ray; setupRay(ray, org, dir);
-    Woop woop; woopSetup(dir, woop);
-    const bool negX = ray.id.x < 0.0f, negY = ray.id.y < 0.0f, negZ = ray.id.z < 0.0f;
-    const unsigned int oct = (negX ? 1u : 0u) | (negY ? 2u : 0u) | (negZ ? 4u : 0u);
-    int node = 0;
-    size_t sp = 0;
-    bool done = false;
-    uint64_t guard = 0;
-    while (!done && node != SENTINEL && ++guard < (1ull << 26))
-    {
-      const float* w = nodes8 + 20 * (size_t) node;
-      ++counts[0];
-      const unsigned int head = asUint(w[3]);
-      const unsigned int imask = head >> 24;
-      const float a[3] = {ldexpf(ray.id.x, (int) (int8_t) (head & 0xffu)), ldexpf(ray.id.y, (int) (int8_t) ((head >> 8) & 0xffu)), ldexpf(ray.id.z, (int) (int8_t) ((head >> 16) & 0xffu))};
-      const float b[3] = {fmaf(w[0], ray.id.x, -ray.ood.x), fmaf(w[1], ray.id.y, -ray.ood.y), fmaf(w[2], ray.id.z, -ray.ood.z)};
-      const bool neg[3] = {negX, negY, negZ};
-      unsigned int hits = 0;
-      for (int k = 0; k < 8; ++k)
-      {
-        float qn[3], qf[3];
-        for (int c = 0; c < 3; ++c)
-        {
-          // words: [8 + 2c + (k >> 2)] lower planes of axis c, [14 + 2c + (k >> 2)] upper planes
-          const float ql = (float) ((asUint(w[8 + 2 * c + (k >> 2)]) >> (8 * (k & 3))) & 0xffu);
-          const float qh = (float) ((asUint(w[14 + 2 * c + (k >> 2)]) >> (8 * (k & 3))) & 0xffu);
-          qn[c] = neg[c] ? qh : ql; qf[c] = neg[c] ? ql : qh;
-        }
-        float tn;
-        if (slabTestGrid(a, b, qn, qf, tmin, bestT, tn)) hits |= 1u << k;
-      }
-      const unsigned int hitLeaf = hits & ~imask;
-      unsigned int hitInner = hits & imask;
-      { const unsigned int t = ((hitInner >> 1) ^ hitInner) & (negX ? 0x55u : 0u); hitInner ^= t | (t << 1); }
-      { const unsigned int t = ((hitInner >> 2) ^ hitInner) & (negY ? 0x33u : 0u); hitInner ^= t | (t << 2); }
-      { const unsigned int t = ((hitInner >> 4) ^ hitInner) & (negZ ? 0x0fu : 0u); hitInner ^= t | (t << 4); }
-      // the next node: from this node's entry if an inner child was hit, from the top of the stack otherwise
-      int next = SENTINEL;
-      {
-        const bool fresh = hitInner != 0u;
-        if (fresh || sp > 0)
-        {
-          int gBase; unsigned int gBits;
-          if (fresh) { gBase = asInt(w[4]); gBits = hitInner | (imask << 8); }
-          else { --sp; gBase = stackBase[sp]; gBits = stackBits[sp]; }
-          unsigned int order = 7; while (!((gBits >> order) & 1u)) --order;
-          const unsigned int rest = gBits & ~(1u << order);
-          const unsigned int childSlot = order ^ oct;
-          next = gBase + __builtin_popcount((gBits >> 8) & ((1u << childSlot) - 1u));
-          if (rest & 0xffu)
-          {
-            stackBase[sp] = gBase; stackBits[sp] = rest; ++sp;
-            if (sp + 8 > stackBase.size()) { stackBase.resize(stackBase.size() * 2); stackBits.resize(stackBits.size() * 2); }
-            if (sp > counts[3]) counts[3] = sp;
-          }
-        }
-      }
-      // the triangles of the leaf children whose boxes were hit, in slot order
-      const int triBase = asInt(w[5]);
-      for (int sl = 0; sl < 8 && !done; ++sl)
-      {
-        if (!((hitLeaf >> sl) & 1u)) continue;
-        const unsigned int meta = (asUint(w[6 + (sl >> 2)]) >> (8 * (sl & 3))) & 0xffu;
-        const int first = triBase + (int) (meta & 31u), last = first + (int) (meta >> 5);
-        for (int ts = first; ts <= last; ++ts)
-        {
-          const float* tri = triangles + 12 * (size_t) ts;
-          ++counts[1];
-          float t, beta, gamma;
-          if (!woopIntersect(woop, ray.o, tri, tri + 4, tri + 8, tmin, t, beta, gamma)) continue;
-          const int prim = asInt(tri[3]), inst = asInt(tri[7]);
-          const bool closer = (t < bestT) || (t == bestT && bestInstance >= 0 && (inst < bestInstance || (inst == bestInstance && prim < bestPrimitive)));
-          if (closer) { bestT = t; bestBeta = beta; bestGamma = gamma; bestInstance = inst; bestPrimitive = prim; if (anyHit) { done = true; break; } }
-        }
-      }
-      node = next;
-    }
-    if (anyHit)
-    {
-      tBetaGamma[3 * i] = tBetaGamma[3 * i + 1] = tBetaGamma[3 * i + 2] = 0.0f;
-      ids[2 * i] = (bestInstance >= 0) ? 1 : 0; ids[2 * i + 1] = -1;
-    }
-    else
-    {
-      tBetaGamma[3 * i] = bestT; tBetaGamma[3 * i + 1] = bestBeta; tBetaGamma[3 * i + 2] = bestGamma;
-      ids[2 * i] = bestInstance; ids[2 * i + 1] = bestPrimitive;
-    }
-  }
-  return 0;
-}
 
 } // extern "C"

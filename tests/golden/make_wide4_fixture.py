@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/wide8_small_room.npz (and, with `4` as argument, wide4_small_room.npz: the quantised 4-ary nodes the
-product ships with) ON THE GPU BOX: the nodes and the triangle slots twk_build produced for a small Cornell room (spheres
-24 x 12), a fixed set of rays, and the hit records of the persistent kernel for them. The CPU suite walks this tree with oracle/same_bvh_walk.cpp (orc_walk_same_bvh8) and compares with the device's records
+"""Generates tests/golden/wide4_small_room.npz ON THE GPU BOX: the quantised 4-ary nodes and the triangle slots twk_build
+produced for a small Cornell room (spheres 24 x 12), a fixed set of rays, and the hit records of the persistent kernel for
+them. The CPU suite walks this tree with oracle/same_bvh_walk.cpp (orc_walk_same_bvh) and compares with the device's records
 and with the oracle's brute force over the same scene (tests/test_oracle_golden.py). Data only: arrays.
-usage (GPU box): python tests/golden/make_wide8_fixture.py [8|4]"""
+usage (GPU box): python tests/golden/make_wide4_fixture.py"""
 import os
 import sys
 
@@ -11,9 +11,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-WIDTH = 4 if (len(sys.argv) > 1 and sys.argv[1] == "4") else 8
+WIDTH = 4
 if __name__ == "__main__":
-    os.environ["TWK_WIDE8"] = "1" if WIDTH == 8 else "0"
     os.environ["TWK_TILE_ENTRIES"] = "0"
 import tweeker_raytracer_amd as twk  # noqa: E402
 
@@ -41,7 +40,7 @@ if __name__ == "__main__":
     dev = twk.Device(ordinal=0, miss=app.info.miss)
     app.initDevice(dev)
     info, nodes, tris, inst = dev.readAcceleration()
-    assert info["nodeFloats"] == (20 if WIDTH == 8 else 16)
+    assert info["nodeFloats"] == 16
     rays = fixture_rays()
     dev.statsEnable(True)
     dev.statsGet(True)

@@ -136,10 +136,9 @@ def _subset_oracle(orc, app, tess):
     return sub, maps
 
 
-@pytest.mark.parametrize("tess,blocks,wide8", [(1000, 6, "0"), (1000, 7, "0"), (2800, 6, "0"), (2800, 7, "0"), (1000, 6, "1"), (1000, 7, "1"), (2800, 6, "1"), (2800, 7, "1")])
-def test_big_room_windows_path_rays_and_overflow_against_the_oracle(twk, orc, monkeypatch, tess, blocks, wide8):
+@pytest.mark.parametrize("tess,blocks", [(1000, 6), (1000, 7), (2800, 6), (2800, 7)])
+def test_big_room_windows_path_rays_and_overflow_against_the_oracle(twk, orc, monkeypatch, tess, blocks):
     monkeypatch.setenv("TWK_TRACE_WAVES_RUNTIME", str(blocks))  # read at twk_device_create: which build of the persistent kernel runs
-    monkeypatch.setenv("TWK_WIDE8", wide8)                      # the quantised 4-ary nodes, or the compressed 8-ary ones (csrc/bvh_wide8.hip)
     app = _app(twk, tess)
     width, height = app.info.resolution[0], app.info.resolution[1]
     assert (width, height) == (1920, 1080)
@@ -147,7 +146,6 @@ def test_big_room_windows_path_rays_and_overflow_against_the_oracle(twk, orc, mo
     app.initDevice(dev)
     info = dev.buildInfo()
     assert info["traceBlocksPerCU"] == blocks and info["triangleSlots"] > (1_900_000 if tess == 1000 else 15_000_000)
-    assert (info["wide8Nodes"] > 0) == (wide8 == "1")
     ref = orc.Oracle(miss=app.info.miss)
     ref.loadApplication(app)
 
@@ -181,10 +179,9 @@ def test_big_room_windows_path_rays_and_overflow_against_the_oracle(twk, orc, mo
     rec, inst, occ = dev.debugTraceQueue(closest, shadow)
     query_stats = dev.statsGet(True)
     dev.statsEnable(False)
-    print(f"tess {tess}, {blocks} blocks per CU, wide8 {wide8} ({info['wide8Nodes']} nodes, {info['wide8Levels']} levels): frame overflow rays {frame_stats['overflowRays']} of {frame_stats['radianceRays'] + frame_stats['shadowRays']}, "
+    print(f"tess {tess}, {blocks} blocks per CU: frame overflow rays {frame_stats['overflowRays']} of {frame_stats['radianceRays'] + frame_stats['shadowRays']}, "
           f"query overflow rays {query_stats['overflowRays']} of {closest.shape[0] + shadow.shape[0]}, deepest ray {query_stats['maxNodesPerRay']} node steps, dropped pushes {query_stats['droppedStackPushes']}")
-    if wide8 == "0":  # (the 8-ary nodes keep ONE stack entry per level: these rays stay within the LDS stack there)
-        assert query_stats["overflowRays"] > 0, "the pole rays are built to outgrow the LDS stack: the HBM-continued traversal is what is checked here"
+    assert query_stats["overflowRays"] > 0, "the pole rays are built to outgrow the LDS stack: the HBM-continued traversal is what is checked here"
     assert query_stats["droppedStackPushes"] == 0 and frame_stats["droppedStackPushes"] == 0
     _, _, tris, _ = dev.readAcceleration()
     slot_primitive = tris[:, 3].view(np.int32)

@@ -320,8 +320,8 @@ def test_pass_is_split_when_its_streams_do_not_fit(twk, monkeypatch):
     dev.close()
 
 
-@pytest.mark.parametrize("scene_file,two_level,wide8", [("scene_rtigo3_cornell_box.txt", False, "0"), ("scene_rtigo3_instances.txt", True, "0"), ("scene_rtigo3_cornell_box.txt", False, "1")])
-def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, monkeypatch, scene_file, two_level, wide8):
+@pytest.mark.parametrize("scene_file,two_level", [("scene_rtigo3_cornell_box.txt", False), ("scene_rtigo3_instances.txt", True)])
+def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, monkeypatch, scene_file, two_level):
     """(Primary rays start at their tile's entry points since round 3 and visit fewer nodes than a walk from the root: the
     walker's counts are compared with the kernel's with that shortcut off, TWK_TILE_ENTRIES=0; the hit records with it on
     are compared in tests/test_gpu_pass_variants.py.)
@@ -334,11 +334,10 @@ def test_same_bvh_host_walker_hits_and_visit_counts(twk, orc, monkeypatch, scene
                         "lensShader 0", "center 0 1 0", "camera 0.75 0.5 45 3.41" if not two_level else "camera 0.75 0.55 50 14"]) + "\n"
     app = twk.Application(system_text=system, scene_text=open(scene_path(scene_file)).read())
     monkeypatch.setenv("TWK_TILE_ENTRIES", "0")
-    monkeypatch.setenv("TWK_WIDE8", wide8)  # "1": the compressed 8-ary nodes and the walker's orc_walk_same_bvh8
     dev = twk.Device(ordinal=0, miss=app.info.miss)
     app.initDevice(dev)
     acc = dev.readAcceleration()
-    assert bool(acc[0]["twoLevel"]) == two_level and acc[0]["nodeFloats"] == (20 if wide8 == "1" else 16)
+    assert bool(acc[0]["twoLevel"]) == two_level and acc[0]["nodeFloats"] == 16
     dev.debugCapture(True)
     dev.statsEnable(True)
     dev.statsGet(reset=True)

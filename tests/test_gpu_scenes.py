@@ -529,7 +529,6 @@ def test_quantised_boxes_contain_everything_below_them(twk, monkeypatch, scene_f
     system = "\n".join(["resolution 64 40", "tileSize 8 8", "samplesSqrt 1", "miss 0", "light 0", "pathLengths 1 1", "epsilonFactor 500",
                         "lensShader 0", "center 0 1 0", "camera 0.75 0.5 45 3.41"]) + "\n"
     app = twk.Application(system_text=system, scene_text=open(scene_path(scene_file)).read())
-    monkeypatch.setenv("TWK_WIDE8", "0")  # the 4-ary nodes; the compressed 8-ary ones have their own test below
     dev = twk.Device(ordinal=0, miss=app.info.miss)
     app.initDevice(dev)
     info, nodes, tris, inst = dev.readAcceleration()
@@ -585,85 +584,6 @@ def test_quantised_boxes_contain_everything_below_them(twk, monkeypatch, scene_f
     assert checked["nodes"] > 10 and checked["leaves"] > 10
     if info["twoLevel"]:
         assert checked["instances"] > 0
-
-
-def _decode_children8(node):
-    """(lo[8,3], hi[8,3], imask, child base, triangle base, meta[8], unused[8]) of one 80-byte compressed 8-ary node
-    (csrc/device_types.h), float32 arithmetic as the kernel's planes (cell = 2^e exactly)."""
-    origin = node[0:3].astype(np.float32)
-    head = int(node[3:4].view(np.uint32)[0])
-    expo = np.array([head & 0xff, (head >> 8) & 0xff, (head >> 16) & 0xff], np.uint8).view(np.int8).astype(np.int32)
-    cell = np.ldexp(np.float32(1.0), expo).astype(np.float32)
-    imask = head >> 24
-    child_base, tri_base = (int(v) for v in node[4:6].view(np.int32))
-    meta_words = node[6:8].view(np.uint32)
-    words = node[8:20].view(np.uint32)
-    lo, hi, meta = np.zeros((8, 3), np.float32), np.zeros((8, 3), np.float32), np.zeros(8, np.int64)
-    for k in range(8):
-        shift = 8 * (k & 3)
-        ql = np.array([(int(words[2 * c + (k >> 2)]) >> shift) & 0xff for c in range(3)], np.float32)
-        qh = np.array([(int(words[6 + 2 * c + (k >> 2)]) >> shift) & 0xff for c in range(3)], np.float32)
-        lo[k] = origin + ql * cell
-        hi[k] = origin + qh * cell
-        meta[k] = (int(meta_words[k >> 2]) >> shift) & 0xff
-    return lo, hi, imask, child_base, tri_base, meta, lo[:, 0] > hi[:, 0]
-
-
-@pytest.mark.gpu
-def test_compressed_8ary_nodes_contain_everything_below_them(twk, monkeypatch):
-    """The same for the compressed 8-ary nodes (csrc/bvh_wide8.hip, TWK_WIDE8=1): walked breadth-first from node 0, every
-    decoded child box contains every triangle slot below that child; the inner children of a node are childBase + rank in
-    slot order, its leaf children's triangles triBase + offset in slot order; every node and every triangle slot is reached
-    exactly once; empty slots are inverted boxes; the children of a node sit in the slots their octant gives them (a child in
-    slot s lies, on the whole, towards (-1)^bit of s on every axis: checked as a majority over the tree, the assignment is greedy)."""
-    from conftest import scene_path
-    monkeypatch.setenv("TWK_WIDE8", "1")
-    app = twk.Application(scene_path("system_rtigo3_cornell_box.txt"), scene_path("scene_rtigo3_cornell_box.txt"))
-    app.setResolution(32, 32)
-    dev = twk.Device(ordinal=0, miss=app.info.miss)
-    app.initDevice(dev)
-    info, nodes, tris, inst = dev.readAcceleration()
-    build = dev.buildInfo()
-    dev.close()
-    assert info["nodeFloats"] == 20 and info["root"] == 0 and build["wide8Nodes"] == nodes.shape[0] and 3 <= build["wide8Levels"] <= 16
-    verts = tris.reshape(-1, 3, 4)[:, :, :3].astype(np.float64)
-    slot_lo, slot_hi = verts.min(axis=1), verts.max(axis=1)
-    n = nodes.shape[0]
-    decoded = [_decode_children8(nodes[i]) for i in range(n)]
-    geo_lo, geo_hi = np.full((n, 3), np.inf), np.full((n, 3), -np.inf)
-    node_seen, slot_seen = np.zeros(n, np.int64), np.zeros(tris.shape[0], np.int64)
-    node_seen[0] = 1
-    agree = total = 0
-    for i in range(n - 1, -1, -1):  # children have larger indices than their parent (breadth-first numbering): bottom-up in one sweep
-        lo, hi, imask, child_base, tri_base, meta, unused = decoded[i]
-        rank = offset = 0
-        centre = 0.5 * (lo[~unused].min(axis=0) + hi[~unused].max(axis=0))
-        assert (~unused).sum() >= 2 or n == 1, i
-        for k in range(8):
-            if unused[k]:
-                assert np.all(lo[k] > hi[k]) and not (imask >> k) & 1 and meta[k] == 0, (i, k)
-                continue
-            if (imask >> k) & 1:
-                child = child_base + rank
-                rank += 1
-                assert i < child < n, (i, k, child)
-                node_seen[child] += 1
-                b_lo, b_hi = geo_lo[child], geo_hi[child]
-            else:
-                first, count = tri_base + (meta[k] & 31), (meta[k] >> 5) + 1
-                assert (meta[k] & 31) == offset and count <= 4, (i, k, meta[k], offset)
-                offset += count
-                slot_seen[first:first + count] += 1
-                b_lo, b_hi = slot_lo[first:first + count].min(axis=0), slot_hi[first:first + count].max(axis=0)
-            assert np.all(lo[k].astype(np.float64) <= b_lo) and np.all(b_hi <= hi[k].astype(np.float64)), (i, k, lo[k], hi[k], b_lo, b_hi)
-            geo_lo[i], geo_hi[i] = np.minimum(geo_lo[i], b_lo), np.maximum(geo_hi[i], b_hi)
-            side = 0.5 * (lo[k] + hi[k]) - centre
-            for axis in range(3):
-                if abs(side[axis]) > 1e-6:
-                    total += 1
-                    agree += int((side[axis] < 0) == bool((k >> axis) & 1))
-    assert np.all(node_seen == 1) and np.all(slot_seen == 1), "every node and every triangle slot is referenced exactly once"
-    assert agree > 0.7 * total, f"octant slots: {agree} of {total} child offsets point the way their slot says"
 
 
 @pytest.mark.gpu

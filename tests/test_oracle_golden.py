@@ -163,19 +163,17 @@ def test_threaded_render_is_the_same_render(twk, orc):
     assert out[0][1] == out[1][1] and out[0][1]["samples"] == 2 * 96 * 54
 
 
-@pytest.mark.parametrize("width", [8, 4])
-def test_device_built_8ary_tree_fixture_walked_on_the_cpu(twk, orc, width):
-    """(width 4: the same for the quantised 4-ary nodes the product ships with, wide4_small_room.npz and orc_walk_same_bvh.)
-    tests/golden/wide8_small_room.npz (made on the GPU box by tests/golden/make_wide8_fixture.py): the compressed 8-ary nodes and
+def test_device_built_tree_fixture_walked_on_the_cpu(twk, orc):
+    """tests/golden/wide4_small_room.npz (made on the GPU box by tests/golden/make_wide4_fixture.py): the quantised 4-ary nodes and
     triangle slots twk_build produced for a small Cornell room, 4 096 rays, and the persistent kernel's hit records and visit counts
-    for them. Here, without a GPU: the host walker (oracle/same_bvh_walk.cpp orc_walk_same_bvh8) walks that tree — the same hit
+    for them. Here, without a GPU: the host walker (oracle/same_bvh_walk.cpp orc_walk_same_bvh) walks that tree — the same hit
     records bit for bit, the same visit counts (up to the reciprocal of the culling test: v_rcp_f32 there, 1 / d here) — and the
-    oracle's brute force over the same scene, rebuilt here from its description, gives the same hits: the node format, the octant
-    order and the leaf numbering of csrc/bvh_wide8.hip are pinned on the CPU side too."""
+    oracle's brute force over the same scene, rebuilt here from its description, gives the same hits: the node format and the
+    leaf numbering of csrc/bvh_build.hip are pinned on the CPU side too."""
     import importlib.util
-    fx = np.load(os.path.join(GOLDEN, "wide%d_small_room.npz" % width))
+    fx = np.load(os.path.join(GOLDEN, "wide4_small_room.npz"))
     nodes, tris, rays = fx["nodes"], fx["triangles"], fx["rays"]
-    assert nodes.shape[1] == (20 if width == 8 else 16) and tris.shape[1] == 12
+    assert nodes.shape[1] == 16 and tris.shape[1] == 12
     acc = ({"root": int(fx["root"]), "root2": int(fx["root2"]), "nodeFloats": nodes.shape[1]}, nodes, tris, np.zeros((1, 32), np.float32))
     tbg, ids, counts = orc.walk_same_bvh(acc, rays)
     assert np.array_equal(ids[:, 0], fx["device_instance"]) and np.array_equal(ids[:, 1], fx["device_primitive"])
@@ -188,7 +186,7 @@ def test_device_built_8ary_tree_fixture_walked_on_the_cpu(twk, orc, width):
     shadow[:, 7] = np.random.default_rng(3).uniform(0.1, 3.0, rays.shape[0]).astype(np.float32)
     _, occ, _ = orc.walk_same_bvh(acc, shadow, anyHit=True)
     # the scene the fixture was built from, from its description, through the oracle's brute force
-    spec = importlib.util.spec_from_file_location("make_wide8_fixture", os.path.join(GOLDEN, "make_wide8_fixture.py"))
+    spec = importlib.util.spec_from_file_location("make_wide4_fixture", os.path.join(GOLDEN, "make_wide4_fixture.py"))
     # (the generator module imports the product library, which loads without a GPU; only its scene text and rays are used here)
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)

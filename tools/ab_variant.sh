@@ -10,9 +10,9 @@ cd "$(dirname "$0")/../tweeker_raytracer_amd/csrc"
 make -s > /dev/null
 mkdir -p ../../build/$NAME
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-function"
-for f in trace_kernels trace_kernels8 bvh_build bvh_sah bvh_wide8 device_api shade_kernels; do
+for f in trace_kernels bvh_build bvh_sah device_api shade_kernels; do
   ( hipcc $FLAGS "$@" -c $f.hip -o ../../build/$NAME/$f.o 2>&1 | grep -E "error" || true ) &
 done
 wait
-hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/lib_$NAME.so ../../build/$NAME/device_api.o ../../build/$NAME/bvh_build.o ../../build/$NAME/bvh_sah.o ../../build/$NAME/trace_kernels.o ../../build/$NAME/trace_kernels8.o ../../build/$NAME/bvh_wide8.o ../../build/$NAME/shade_kernels.o host/description_parser.o host/triangle_meshes.o host/application.o host/image_files.o host/host_cabi.o -lz
+hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/lib_$NAME.so ../../build/$NAME/device_api.o ../../build/$NAME/bvh_build.o ../../build/$NAME/bvh_sah.o ../../build/$NAME/trace_kernels.o ../../build/$NAME/shade_kernels.o host/description_parser.o host/triangle_meshes.o host/application.o host/image_files.o host/host_cabi.o -lz
 ls -la ../../build/lib_$NAME.so

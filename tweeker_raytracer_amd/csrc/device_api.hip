@@ -28,9 +28,6 @@ void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int
 void launchTraceQuery(const LaunchParams& p, const float* rays, unsigned int numRays, int anyHit, float* tBetaGamma, int* ids, int gridBlocks, hipStream_t stream);
 void launchGenerate(const LaunchParams& p, hipStream_t stream);
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream);
-hipError_t buildWide8(hipStream_t stream, const BvhNode* nodes, int numBinaryNodes, int root, int numTriangles, float4** outNodes, int* outCount, int** outSlotMap, int* outLevels);
-void launchPermuteSlots(const int* slotMap, int count, const float4* triangles, const float4* shade, float4* outTriangles, float4* outShade, hipStream_t stream);
-void launchRemapLeafRefs(BvhNode* nodes, int numNodes, float4* wideQ, int numWide, const int* slotMap, hipStream_t stream);
 void launchTileEntries(const LaunchParams& p, const float4* topTable, int tilesX, int tilesY, int4* out, hipStream_t stream);
 void launchAccumulate(const LaunchParams& p, hipStream_t stream);
 void launchCompositor(const float4* tiles, float4* output, int width, int height, int launchWidth, int deviceCount,
@@ -119,8 +116,6 @@ struct TwkDevice_t
   BvhNode* d_nodes = nullptr; BvhNode* d_wideNodes = nullptr /* build-time only: full-precision wide nodes, freed once quantised */; float4* d_wideQ = nullptr; float4* d_triangles = nullptr; float4* d_shadeTriangles = nullptr; DevInstance* d_instances = nullptr;
   bool directSmallLeaves = true; /* TWK_DIRECT_SMALL_LEAVES=0: A/B */ bool costedCuts = true; /* TWK_COSTED_CUTS=0: A/B */ bool fusedPrimary = true; /* TWK_FUSED_PRIMARY=0: A/B */ bool tileEntries = true; /* TWK_TILE_ENTRIES=0: A/B */ bool wideRoot = true; /* TWK_WIDE_ROOT=0: A/B */ int wideRoot1 = 0, wideRoot2 = TWK_BVH_SENTINEL; size_t wideNodesTotal = 0;
   int4* d_tileEntries = nullptr; size_t tileEntriesCapacity = 0; TileEntriesKey tileEntriesKey = {}; uint64_t buildSerial = 0; // entry points of the primary rays (trace_kernels.hip tileEntryKernel) and what they were built for
-  // compressed 8-ary nodes (bvh_wide8.hip): built for flattened scenes when wide8Mode says so; TWK_WIDE8 = 0 never, 1 wherever the scene is flattened, unset: by scene size (chooseWide8)
-  float4* d_wide8 = nullptr; int wide8Count = 0, wide8Levels = 0, wide8Mode = -1;
   float4* d_topNodes = nullptr; float4* d_topNodes7 = nullptr; bool topCache = true; int traceWavesForced = 0 /* TWK_TRACE_WAVES_RUNTIME: 6 or 7, 0 = by scene */; // TWK_TOP_CACHE=0 turns the LDS top-of-tree cache off (A/B)
   float4* d_texels[3] = {nullptr, nullptr, nullptr};
   float* d_envCDF_U = nullptr; float* d_envCDF_V = nullptr;
@@ -253,7 +248,6 @@ static void refreshParams(TwkDevice dev)
   p.materials = dev->d_materials; p.lights = dev->d_lights; p.camera = dev->d_camera;
   p.tlasRoot = dev->tlasRoot;
   p.topNodes = dev->d_topNodes; p.topNodes7 = dev->d_topNodes7;
-  p.wide8 = dev->twoLevel ? nullptr : dev->d_wide8; p.wide8Count = dev->wide8Count;
   p.topRoot = dev->topCache ? (TWK_NODE_CACHED | 0) : dev->wideRoot1;
   p.topRoot2 = (dev->wideRoot2 == TWK_BVH_SENTINEL) ? TWK_BVH_SENTINEL : (dev->topCache ? (TWK_NODE_CACHED | 1) : dev->wideRoot2);
   p.twoLevel = dev->twoLevel ? 1 : 0;
@@ -266,7 +260,6 @@ static void refreshParams(TwkDevice dev)
   // seven trace blocks per CU where the variant that fits them applies (device_types.h TWK_TRACE_WAVES7)
   p.traceWaves = (!dev->twoLevel && (!p.hasCutout || TWK_TRACE_WAVES_CUTOUT == TWK_TRACE_WAVES7) && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : (p.hasCutout ? (dev->twoLevel ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES) : TWK_TRACE_WAVES);
   if (dev->traceWavesForced == TWK_TRACE_WAVES || (dev->traceWavesForced == TWK_TRACE_WAVES7 && !dev->twoLevel)) p.traceWaves = dev->traceWavesForced;
-  if (p.hasCutout && p.wide8 != nullptr && p.traceWaves == TWK_TRACE_WAVES7) p.traceWaves = TWK_TRACE_WAVES; // the 8-ary cutout build has no seven-block form (trace_kernels8.hip)
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)
   {
@@ -607,7 +600,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   p.tileEntries = nullptr; p.tilesX = 0;
   const bool distributed = p.distribution && 1 < p.deviceCount;
   const bool tilesAlign = !distributed || (p.tileSize[0] % TWK_ENTRY_TILE == 0 && p.tileSize[1] % TWK_ENTRY_TILE == 0); // a distribution tile = whole entry tiles
-  if (fusedPrimary && dev->tileEntries && p.wide8 == nullptr && p.lensShader == 0 && tilesAlign && (distributed || p.launchWidth == p.resolution[0]) && !dev->cameras.empty())
+  if (fusedPrimary && dev->tileEntries && p.lensShader == 0 && tilesAlign && (distributed || p.launchWidth == p.resolution[0]) && !dev->cameras.empty())
   {
     const int tilesX = (p.launchWidth + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE, tilesY = (p.resolution[1] + TWK_ENTRY_TILE - 1) / TWK_ENTRY_TILE;
     const size_t need = (size_t) tilesX * tilesY * 2;
@@ -758,7 +751,6 @@ try
   if (const char* e = getenv("TWK_FUSED_PRIMARY")) dev->fusedPrimary = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TILE_ENTRIES")) dev->tileEntries = (atoi(e) != 0);
   if (const char* e = getenv("TWK_WIDE_ROOT")) dev->wideRoot = (atoi(e) != 0);
-  if (const char* e = getenv("TWK_WIDE8")) dev->wide8Mode = (atoi(e) != 0) ? 1 : 0;
   if (const char* e = getenv("TWK_PACKED_QUEUE")) dev->packedQueue = (atoi(e) != 0);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
@@ -780,7 +772,7 @@ try
   for (TimedLaunch& t : dev->timed) { (void) hipEventDestroy(t.start); (void) hipEventDestroy(t.stop); }
   freeDevice(dev->d_camera); freeDevice(dev->d_lights); freeDevice(dev->d_materials);
   freeDevice(dev->d_attributes); freeDevice(dev->d_indices);
-  freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_wide8); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
+  freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   for (int k = 0; k < 3; ++k) freeDevice(dev->d_texels[k]);
   freeDevice(dev->d_envCDF_U); freeDevice(dev->d_envCDF_V); freeDevice(dev->d_topNodes); freeDevice(dev->d_topNodes7); freeDevice(dev->d_tileEntries);
   freeDevice(dev->d_streamBlock); freeDevice(dev->d_outputInternal);
@@ -1097,8 +1089,7 @@ try
   if (numTris >= ((size_t) 1 << 28) || numAttr >= ((size_t) 1 << 31) || numIdx >= ((size_t) 1 << 31))
     return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_build: " + std::to_string(numTris) + " triangle slots; a leaf reference holds 28 bits of slot index");
 
-  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_wide8); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
-  dev->wide8Count = 0; dev->wide8Levels = 0;
+  freeDevice(dev->d_attributes); freeDevice(dev->d_indices); freeDevice(dev->d_nodes); freeDevice(dev->d_wideNodes); freeDevice(dev->d_wideQ); freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles); freeDevice(dev->d_instances);
   HIP_TRY(hipMalloc(&dev->d_attributes, sizeof(TwkTriangleAttributes) * numAttr));
   HIP_TRY(hipMalloc(&dev->d_indices, sizeof(unsigned int) * numIdx));
   HIP_TRY(hipMalloc(&dev->d_nodes, sizeof(BvhNode) * numNodes));
@@ -1231,26 +1222,6 @@ try
     if (has) { dev->wideRoot1 = (int) numNodes; dev->wideRoot2 = (int) numNodes + 1; dev->wideNodesTotal = numNodes + 2; }
   }
   launchQuantizeWide(dev->d_wideNodes, dev->d_wideQ, (int) dev->wideNodesTotal, dev->stream);
-  // Compressed 8-ary nodes over the same binary tree, for a scene whose instances are all flattened (bvh_wide8.hip). Their leaf
-  // children address consecutive triangle slots, so the triangle slots and shading records are permuted into that order and
-  // the leaf references of the binary and the 4-ary nodes follow them: every traversal of the scene sees the same slots.
-  const bool wantWide8 = (numEntered == 0) && (dev->wide8Mode == 1 || (dev->wide8Mode < 0 && TWK_WIDE8_DEFAULT));
-  if (wantWide8)
-  {
-    int* slotMap = nullptr;
-    HIP_TRY(buildWide8(dev->stream, dev->d_nodes, (int) numNodes, dev->tlasRoot, (int) numTris, &dev->d_wide8, &dev->wide8Count, &slotMap, &dev->wide8Levels));
-    ScopedDeviceBuffer<int> slotMapOwner; slotMapOwner.ptr = slotMap;
-    float4* triangles = nullptr; float4* shade = nullptr;
-    HIP_TRY(hipMalloc(&triangles, sizeof(float4) * 3 * numTris));
-    if (hipMalloc(&shade, sizeof(float4) * TWK_SHADE_RECORD * numTris) != hipSuccess) { (void) hipFree(triangles); return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "twk_build: out of memory for the permuted shading records"); }
-    launchPermuteSlots(slotMap, (int) numTris, dev->d_triangles, dev->d_shadeTriangles, triangles, shade, dev->stream);
-    launchRemapLeafRefs(dev->d_nodes, (int) numNodes, dev->d_wideQ, (int) dev->wideNodesTotal, slotMap, dev->stream);
-    const hipError_t e = hipStreamSynchronize(dev->stream);
-    if (e != hipSuccess) { (void) hipFree(triangles); (void) hipFree(shade); HIP_TRY(e); }
-    freeDevice(dev->d_triangles); freeDevice(dev->d_shadeTriangles);
-    dev->d_triangles = triangles; dev->d_shadeTriangles = shade;
-    info.wide8Nodes = (uint64_t) dev->wide8Count; info.wide8Levels = (uint64_t) dev->wide8Levels;
-  }
   if (!dev->d_topNodes) HIP_TRY(hipMalloc(&dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
   if (!dev->d_topNodes7) HIP_TRY(hipMalloc(&dev->d_topNodes7, sizeof(float4) * 4 * TWK_TOP_NODES7));
   launchTopCache(dev->d_wideQ, dev->wideRoot1, dev->wideRoot2, dev->d_topNodes, TWK_TOP_NODES, dev->stream);
@@ -1750,12 +1721,11 @@ try
   int rc = activate(dev, "twk_debug_read_acceleration"); if (rc) return rc;
   if (!info) return twkSetError(TWK_ERROR_INVALID_VALUE, "twk_debug_read_acceleration: NULL info");
   if (!dev->built) return twkSetError(TWK_ERROR_INVALID_STATE, "twk_debug_read_acceleration: twk_build has not been called");
-  const bool wide8 = !dev->twoLevel && dev->d_wide8 != nullptr; // what the persistent kernel walks: the compressed 8-ary nodes (root = node 0), or the quantised 4-ary ones
-  info->root = wide8 ? 0 : dev->wideRoot1; info->twoLevel = dev->twoLevel ? 1 : 0;
-  info->root2 = (wide8 || dev->wideRoot2 == TWK_BVH_SENTINEL) ? -1 : dev->wideRoot2; info->nodeFloats = wide8 ? 4 * TWK_WIDE8_FLOAT4 : 16;
-  info->numNodes = wide8 ? (uint64_t) dev->wide8Count : (uint64_t) dev->wideNodesTotal; info->numTriangleSlots = dev->totalTriangles; info->numInstances = dev->instances.size(); // 4-ary nodes: the binary nodes' + the two of an 8-wide root
+  info->root = dev->wideRoot1; info->twoLevel = dev->twoLevel ? 1 : 0;
+  info->root2 = (dev->wideRoot2 == TWK_BVH_SENTINEL) ? -1 : dev->wideRoot2; info->nodeFloats = 16;
+  info->numNodes = (uint64_t) dev->wideNodesTotal; info->numTriangleSlots = dev->totalTriangles; info->numInstances = dev->instances.size(); // 4-ary nodes: the binary nodes' + the two of an 8-wide root
   HIP_TRY(hipStreamSynchronize(dev->stream));
-  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, wide8 ? dev->d_wide8 : dev->d_wideQ, sizeof(float) * (size_t) info->nodeFloats * info->numNodes, hipMemcpyDeviceToHost));
+  if (wideNodes) HIP_TRY(hipMemcpy(wideNodes, dev->d_wideQ, sizeof(float) * (size_t) info->nodeFloats * info->numNodes, hipMemcpyDeviceToHost));
   if (triangles) HIP_TRY(hipMemcpy(triangles, dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles, hipMemcpyDeviceToHost));
   if (instances) HIP_TRY(hipMemcpy(instances, dev->d_instances, sizeof(DevInstance) * dev->instances.size(), hipMemcpyDeviceToHost));
   return TWK_SUCCESS;
@@ -1782,7 +1752,6 @@ try
   };
   q.nodes          = static_cast<const BvhNode*>(host(dev->d_nodes, sizeof(BvhNode) * dev->totalNodes));
   q.wideQ          = static_cast<const float4*>(host(dev->d_wideQ, sizeof(float4) * 4 * dev->wideNodesTotal));
-  q.wide8 = nullptr; q.wide8Count = 0; // the host build walks the binary nodes (trace_device.h traverse)
   q.topNodes       = static_cast<const float4*>(host(dev->d_topNodes, sizeof(float4) * 4 * TWK_TOP_NODES));
   q.topNodes7      = static_cast<const float4*>(host(dev->d_topNodes7, sizeof(float4) * 4 * TWK_TOP_NODES7));
   q.triangles      = static_cast<const float4*>(host(dev->d_triangles, sizeof(float4) * 3 * dev->totalTriangles));

@@ -138,32 +138,6 @@ struct __attribute__((aligned(16))) BvhNode
 #endif
 #define TWK_TOP_STRIDE 5 // float4 per cached node (4 used)
 
-// Compressed 8-ary node of the persistent trace kernel's WIDE8 builds (bvh_wide8.hip; after Ylitie, Karras, Laine 2017), for
-// scenes whose instances are all flattened: 80 bytes = five float4.
-//   [0] origin.xyz of the node's box, then ONE word: exponent bytes ex | ey << 8 | ez << 16 (signed: cell = 2^e, the smallest
-//       power of two with extent / cell < 254) | imask << 24 (bit s: slot s holds an inner child)
-//   [1] childBase (node index of the first inner child: the inner children are stored contiguously in slot order, child of slot
-//       s = childBase + popcount(imask & ((1 << s) - 1))), triBase (first triangle slot of the node's leaf children, also
-//       contiguous in slot order), meta bytes of slots 0..3, of slots 4..7: a leaf child's triangles are the slots
-//       triBase + (meta & 31) .. + (meta >> 5); inner and empty slots: 0
-//   [2] qlo.x slots 0..3, 4..7, qlo.y 0..3, 4..7      one byte per slot: child box = origin + q * cell, rounded outwards;
-//   [3] qlo.z 0..3, 4..7, qhi.x 0..3, 4..7             an empty slot has the inverted box lo = 255, hi = 0 (never entered)
-//   [4] qhi.y 0..3, 4..7, qhi.z 0..3, 4..7
-// Slots are assigned by octant (the child that lies towards (-1)^bit0 x, (-1)^bit1 y, (-1)^bit2 z of the node's centre gets
-// slot s), so a ray whose direction has the sign bits `oct` (bit k: component k negative) meets the children roughly in the
-// order of decreasing (s ^ oct): ONE stack entry per node — (childBase, hit mask in that order | imask << 8) — and the next
-// child by find-first-bit, instead of four references sorted by entry distance. The nodes are numbered breadth-first: the
-// first TWK_TOP8_NODES of the array are the top of the tree and are read from an LDS copy.
-#define TWK_WIDE8_FLOAT4 5
-#ifndef TWK_WIDE8_DEFAULT
-#define TWK_WIDE8_DEFAULT 0 // with TWK_WIDE8 unset: build and walk the 8-ary nodes for every flattened scene (1) or for none (0)
-#endif
-#ifndef TWK_TOP8_NODES
-#define TWK_TOP8_NODES 44
-#endif
-#define TWK_TRACE_STACK8      11  // (childBase, mask) entries per lane in LDS, six-block build: 23 rows of 1 KiB + 3.4 KiB of cached nodes = 26.4 of 26.5 KiB
-#define TWK_TRACE_STACK8_W7   9   // seven-block build: 19 rows + 3.4 KiB = 22.4 of 22.5 KiB
-
 // Everything a kernel needs; passed by value (≙ SystemData, shaders/system_data.h:40-90).
 struct LaunchParams
 {
@@ -174,8 +148,6 @@ struct LaunchParams
   int                topRoot;        // reference the persistent kernel starts at: TWK_NODE_CACHED | 0, or tlasRoot when the cache is off
   int                topRoot2;       // the second node of an 8-wide root (bvh_build.hip wideRootKernel), on every ray's stack at its start; TWK_BVH_SENTINEL: none
   const float4*      wideQ;          // quantised 4-ary nodes, 64 bytes = 4 float4 per inner node index (persistent trace kernel; layout above)
-  const float4*      wide8;          // compressed 8-ary nodes, 80 bytes = 5 float4 each, breadth-first from node 0 (WIDE8 builds of the trace kernel); nullptr: the 4-ary nodes are traversed
-  int                wide8Count;     // number of 8-ary nodes (the first min(wide8Count, TWK_TOP8_NODES) are cached in LDS)
   const float4*      triangles;      // 3 per triangle slot: the vertices, .w of the first = primitive id, of the second = instance (world-space slots)
   const float4*      shadeTriangles; // TWK_SHADE_RECORD (8) per triangle slot, 128 B: geometric normal + the three vertices' normals | tangents | texcoords (bvh_build.hip emitTrianglesKernel)
   const DevInstance* instances;

@@ -1,5 +1,5 @@
 // Launchers of the persistent traversal kernel (trace_persistent.h) for the 4-ary nodes, the stand-alone query kernel and the
-// entry points of the primary rays. The builds over the compressed 8-ary nodes are instantiated in trace_kernels8.hip.
+// entry points of the primary rays.
 #include "trace_persistent.h"
 
 namespace twk {
@@ -41,12 +41,9 @@ static void launchTraceOpaque(const LaunchParams& p, int depth, int gridBlocks, 
 
 // gridBlocks must be numCUs x p.traceWaves (or a lane's share of it): every block of the persistent kernel resident at once.
 // primary: depth 0 of a pass whose generateKernel was skipped.
-void launchTrace8(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream); // trace_kernels8.hip
-
 
 void launchTrace(const LaunchParams& p, int depth, bool count, bool primary, int gridBlocks, hipStream_t stream)
 {
-  if (p.wide8 != nullptr && !p.twoLevel) { launchTrace8(p, depth, count, primary, gridBlocks, stream); return; } // the builds over the compressed 8-ary nodes
   if (!p.hasCutout)
   {
     if (primary) { if (count) launchTraceOpaque<true, true>(p, depth, gridBlocks, stream);  else launchTraceOpaque<false, true>(p, depth, gridBlocks, stream); }

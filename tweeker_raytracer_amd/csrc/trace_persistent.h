@@ -95,30 +95,18 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
 // W7: the seven-blocks-per-CU build of the kernel (device_types.h TWK_TRACE_WAVES7): a 19-entry LDS stack, a 32-node cache.
 // PRIMARY: depth 0 of a pass without generateKernel — the lane computes the primary ray of its slot instead of fetching it
 // (shade_kernels.hip "primary rays"). With CUTOUT the seed is stored in queue 0 for the opacity draws.
-// WIDE8: the tree is walked over the compressed 8-ary nodes (device_types.h, bvh_wide8.hip; flattened scenes only): one
-// (childBase, hit mask) stack entry per node, children in octant order, the triangles of a node's leaf children tested
-// before its inner children are entered.
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY, bool WIDE8>
+// (The builds over compressed 8-ary nodes, round 4, lost on every scene and live in tools/experiments/r04_wide8_nodes.patch.)
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
 __global__ void __launch_bounds__(TWK_TRACE_BLOCK, W7 ? TWK_TRACE_WAVES7 : (CUTOUT ? ((PRIMARY || TWO_LEVEL) ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES) : ((PRIMARY && TWO_LEVEL) ? TWK_TRACE_WAVES_PRIMARY_TWO_LEVEL : (PRIMARY ? TWK_TRACE_WAVES_PRIMARY : TWK_TRACE_WAVES)))) // blocks per CU = waves per SIMD: device_types.h
 traceKernel(LaunchParams p, int depth)
 {
-  static_assert(!(WIDE8 && TWO_LEVEL), "the 8-ary nodes are built for flattened scenes");
-  constexpr int STACK_LDS = WIDE8 ? (W7 ? TWK_TRACE_STACK8_W7 : TWK_TRACE_STACK8) : (W7 ? TWK_TRACE_STACK_LDS7 : TWK_TRACE_STACK_LDS);
-  constexpr int TOP_NODES = WIDE8 ? TWK_TOP8_NODES : (W7 ? TWK_TOP_NODES7 : TWK_TOP_NODES);
-  // WIDE8: an entry is two words — mask word of entry e in row e, childBase in row 2 * STACK_LDS - e, row STACK_LDS the dummy of both
-  constexpr int STACK_ROWS = WIDE8 ? (2 * STACK_LDS + 1) : (STACK_LDS + 1); // + 1 dummy row, see the node step
+  constexpr int STACK_LDS = W7 ? TWK_TRACE_STACK_LDS7 : TWK_TRACE_STACK_LDS;
+  constexpr int TOP_NODES = W7 ? TWK_TOP_NODES7 : TWK_TOP_NODES;
+  constexpr int STACK_ROWS = STACK_LDS + 1; // + 1 dummy row, see the node step
   __shared__ int stackStorage[STACK_ROWS * TWK_TRACE_BLOCK];
   __shared__ float4 topCache[TOP_NODES * TWK_TOP_STRIDE];         // device_types.h TWK_NODE_CACHED / TWK_TOP8_NODES
   int* ldsStack = stackStorage + threadIdx.x;
   const int stride = TWK_TRACE_BLOCK;
-  const int top8 = WIDE8 ? min(p.wide8Count, TOP_NODES) : 0; // WIDE8: nodes [0, top8) are read from LDS (breadth-first numbering: the top of the tree)
-  if (WIDE8)
-  {
-    static_assert(TWK_TOP_STRIDE == TWK_WIDE8_FLOAT4, "a cached 8-ary node fills its slot");
-    for (int i = threadIdx.x; i < TOP_NODES * TWK_WIDE8_FLOAT4; i += TWK_TRACE_BLOCK)
-      topCache[i] = (i < top8 * TWK_WIDE8_FLOAT4) ? p.wide8[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-  else
   {
     const float4* topSource = W7 ? p.topNodes7 : p.topNodes;
     for (int i = threadIdx.x; i < TOP_NODES * 4; i += TWK_TRACE_BLOCK) topCache[(i >> 2) * TWK_TOP_STRIDE + (i & 3)] = topSource[i];
@@ -184,10 +172,7 @@ traceKernel(LaunchParams p, int depth)
     ST_DONE       = 4u,  // the ray completed in this round and its result is not yet written
     ST_SHADOW     = 8u,  // slot belongs to the shadow queue
     ST_RETRACE    = 16u, // LDS stack overflow: the ray is re-traced by traceOverflowKernel with the spilling traverse()
-    ST_OVERFLOWED = 32u, // set while the overflowed ray is handed over (nothing is written for it here)
-    // WIDE8: bits 8-15 = the leaf children of the lane's last node whose boxes were hit and whose triangles wait for the triangle
-    // phase; bits 16-18 = the sign bits of the ray direction (x, y, z: the octant that orders a node's children)
-    ST_LEAF_HITS  = 0xff00u
+    ST_OVERFLOWED = 32u  // set while the overflowed ray is handed over (nothing is written for it here)
   };
   unsigned int state = 0u;
   unsigned int slot = 0;
@@ -197,7 +182,6 @@ traceKernel(LaunchParams p, int depth)
   TraceRay ray; ray.o = v3(0.0f); ray.d = v3(0.0f); ray.id = v3(0.0f);
   WoopConstants woop; woop.perm = 0u; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
-  int tgBase = 0; unsigned int metaLo = 0u, metaHi = 0u; // WIDE8: first triangle slot and the leaf bytes of the node whose leaf children wait (ST_LEAF_HITS)
   unsigned int guard = 0;
   unsigned int rayClock = 0; // COUNT, time view: shader clock when this lane took its ray
 
@@ -246,8 +230,8 @@ traceKernel(LaunchParams p, int depth)
         res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
         setupRay(ray, org, dir);
         woopSetup(dir, woop);
-        currentInstance = -1; sp = 0; node = WIDE8 ? 0 : p.topRoot; guard = 0;
-        if (!WIDE8 && p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; }
+        currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
+        if (p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; }
         state |= ST_HAS_RAY;
       }
       else if (state & ST_OVERFLOWED) { state &= ~ST_OVERFLOWED; }
@@ -319,7 +303,7 @@ traceKernel(LaunchParams p, int depth)
               d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, pr.active ? RT_DEFAULT_MAX : -1.0f);
               state = ST_HAS_RAY;
               if (CUTOUT) p.raySeedFlags[0][slot] = make_uint2(pr.seed, 0u); // the opacity test of this segment draws from the seed in the queue (cutoutIgnoresCandidate), and shade(0) takes it from there
-              if (!WIDE8 && p.tileEntries != nullptr)
+              if (p.tileEntries != nullptr)
               {
                 const unsigned int launchIndex = (slot + (unsigned int) p.pathBase) % (unsigned int) p.numPixels;
                 const unsigned int lx = launchIndex % (unsigned int) p.launchWidth, ly = launchIndex / (unsigned int) p.launchWidth;
@@ -338,18 +322,10 @@ traceKernel(LaunchParams p, int depth)
             setupRay(ray, org, dir);
             woopSetup(dir, woop); // world-space constants: flattened instances are tested without entering anything
             currentInstance = -1; sp = 0; guard = 0;
-            if (WIDE8)
-            {
-              node = 0; // the 8-ary nodes are numbered breadth-first from the root
-              state |= ((ray.id.x < 0.0f ? 1u : 0u) | (ray.id.y < 0.0f ? 2u : 0u) | (ray.id.z < 0.0f ? 4u : 0u)) << 16;
-            }
-            else
-            {
-              node = p.topRoot;
-              if (p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; } // the root's second node (wideRootKernel)
-            }
+            node = p.topRoot;
+            if (p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; } // the root's second node (wideRootKernel)
             if (COUNT) rayClock = (unsigned int) __builtin_readcyclecounter();
-            if (PRIMARY && !WIDE8 && entryA.x > 0)
+            if (PRIMARY && entryA.x > 0)
             {
               sp = 0; // the tile's list was opened from both nodes of the root
               // the tile's entry points instead of the root: the first goes next, the others wait on the stack, nearest on top
@@ -384,84 +360,6 @@ traceKernel(LaunchParams p, int depth)
       // (a lane without a ray holds node = TWK_BVH_SENTINEL: one comparison decides who steps)
       while ((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL)
       {
-        if constexpr (WIDE8)
-        {
-          // ONE compressed 8-ary node (device_types.h): five 16-byte lane loads — from the LDS copy for the top of the tree (the
-          // nodes are numbered breadth-first). As with the 4-ary nodes, one set of flat loads on a selected pointer.
-          const float4* w = (node < top8) ? (topCache + node * TWK_WIDE8_FLOAT4) : (p.wide8 + TWK_WIDE8_FLOAT4 * (size_t) node);
-          if (COUNT) { if (node < top8) ++cachedCount; }
-          const float4 n0 = w[0], n1 = w[1], n2 = w[2], n3 = w[3], n4 = w[4];
-          ++guard;
-          if (COUNT) ++nodeCount;
-          TWK_WAVE_STEP(nodeWaveSteps)
-          const unsigned int head = __float_as_uint(n0.w); // exponent bytes x, y, z (signed), imask
-          const unsigned int imask = head >> 24;
-          // plane distance of grid coordinate q on one axis: q * (cell / d) + (origin / d - o / d), cell = 2^e
-          const float ax = ldexpf(ray.id.x, (int) (head << 24) >> 24), ay = ldexpf(ray.id.y, (int) (head << 16) >> 24), az = ldexpf(ray.id.z, (int) (head << 8) >> 24);
-          const float bx = __builtin_fmaf(n0.x, ray.id.x, -ray.ood.x), by = __builtin_fmaf(n0.y, ray.id.y, -ray.ood.y), bz = __builtin_fmaf(n0.z, ray.id.z, -ray.ood.z);
-          // near and far plane of each axis by the sign of the ray direction, for four children at a time (their grid coordinates share a word)
-          const bool negX = ray.id.x < 0.0f, negY = ray.id.y < 0.0f, negZ = ray.id.z < 0.0f;
-          const unsigned int qlx0 = __float_as_uint(n2.x), qlx1 = __float_as_uint(n2.y), qly0 = __float_as_uint(n2.z), qly1 = __float_as_uint(n2.w);
-          const unsigned int qlz0 = __float_as_uint(n3.x), qlz1 = __float_as_uint(n3.y), qhx0 = __float_as_uint(n3.z), qhx1 = __float_as_uint(n3.w);
-          const unsigned int qhy0 = __float_as_uint(n4.x), qhy1 = __float_as_uint(n4.y), qhz0 = __float_as_uint(n4.z), qhz1 = __float_as_uint(n4.w);
-          const unsigned int qnx0 = negX ? qhx0 : qlx0, qfx0 = negX ? qlx0 : qhx0, qnx1 = negX ? qhx1 : qlx1, qfx1 = negX ? qlx1 : qhx1;
-          const unsigned int qny0 = negY ? qhy0 : qly0, qfy0 = negY ? qly0 : qhy0, qny1 = negY ? qhy1 : qly1, qfy1 = negY ? qly1 : qhy1;
-          const unsigned int qnz0 = negZ ? qhz0 : qlz0, qfz0 = negZ ? qlz0 : qhz0, qnz1 = negZ ? qhz1 : qlz1, qfz1 = negZ ? qlz1 : qhz1;
-          float tn; // entry distances are not kept: the order of the children comes from their slots
-#define TWK_Q(word, k) ((float) (((word) >> (8 * (k))) & 0xffu)) /* v_cvt_f32_ubyte<k> */
-#define TWK_SLAB8(h, k) slabTestGrid(ax, ay, az, bx, by, bz, TWK_Q(qnx##h, k), TWK_Q(qny##h, k), TWK_Q(qnz##h, k), TWK_Q(qfx##h, k), TWK_Q(qfy##h, k), TWK_Q(qfz##h, k), tmin, res.t, tn)
-          unsigned int hits = TWK_SLAB8(0, 0) ? 1u : 0u;
-          hits |= TWK_SLAB8(0, 1) ? 2u : 0u;
-          hits |= TWK_SLAB8(0, 2) ? 4u : 0u;
-          hits |= TWK_SLAB8(0, 3) ? 8u : 0u;
-          hits |= TWK_SLAB8(1, 0) ? 16u : 0u;
-          hits |= TWK_SLAB8(1, 1) ? 32u : 0u;
-          hits |= TWK_SLAB8(1, 2) ? 64u : 0u;
-          hits |= TWK_SLAB8(1, 3) ? 128u : 0u;
-#undef TWK_SLAB8
-#undef TWK_Q
-          const unsigned int hitLeaf = hits & ~imask; // an empty slot has an inverted box: never hit
-          unsigned int hitInner = hits & imask;
-          // into traversal order: bit p of the mask = slot p ^ oct (the children nearest along the ray in the high bits), three
-          // conditional swaps of bit groups
-          { const unsigned int t = ((hitInner >> 1) ^ hitInner) & (negX ? 0x55u : 0u); hitInner ^= t | (t << 1); }
-          { const unsigned int t = ((hitInner >> 2) ^ hitInner) & (negY ? 0x33u : 0u); hitInner ^= t | (t << 2); }
-          { const unsigned int t = ((hitInner >> 4) ^ hitInner) & (negZ ? 0x0fu : 0u); hitInner ^= t | (t << 4); }
-          // The next node comes from ONE (childBase, mask) entry: the one this node gives if an inner child was hit, the top of
-          // the stack otherwise. Its nearest child is taken; what is left of it goes (back) to the stack — mask word of entry e in
-          // row e, childBase in row 2 * STACK_LDS - e, row STACK_LDS absorbs the stores of a lane that has nothing to keep.
-          const bool fresh = hitInner != 0u;
-          const int pos = fresh ? sp : sp - 1;
-          const bool none = pos < 0; // no inner child hit and an empty stack: no node is left for this ray
-          int gBase = __float_as_int(n1.x);
-          unsigned int gBits = hitInner | (imask << 8);
-          if (!fresh && !none) { gBits = (unsigned int) ldsStack[pos * stride]; gBase = ldsStack[(2 * STACK_LDS - pos) * stride]; }
-          const unsigned int order = (31u - (unsigned int) __clz((int) (gBits & 0xffu))) & 7u; // position of the nearest child in traversal order
-          const unsigned int rest = gBits & ~(1u << order);
-          const unsigned int childSlot = order ^ ((state >> 16) & 7u);
-          const int next = gBase + __popc((gBits >> 8) & ((1u << childSlot) - 1u)); // the inner children are stored in slot order from childBase
-          const bool keep = !none & ((rest & 0xffu) != 0u);
-          const bool fits = pos < STACK_LDS;
-          const int row = (keep & fits) ? pos : STACK_LDS;
-          ldsStack[row * stride] = (int) rest;
-          ldsStack[(2 * STACK_LDS - row) * stride] = gBase;
-          const bool overflow = keep & !fits;
-          sp = none ? 0 : (pos + (keep ? 1 : 0));
-          node = none ? TWK_BVH_SENTINEL : next;
-          bool stop = (guard > (1u << 22));
-          if (hitLeaf != 0u)
-          {
-            // the triangles of the leaf children are tested in the triangle phase, before any inner child is entered; `node`
-            // waits complemented (negative: the lane takes no node step meanwhile)
-            tgBase = __float_as_int(n1.y); metaLo = __float_as_uint(n1.z); metaHi = __float_as_uint(n1.w);
-            state |= hitLeaf << 8;
-            node = ~node;
-          }
-          else stop = stop || none;
-          if (overflow) state |= ST_RETRACE;
-          if (stop | overflow) { state = (state & ~(ST_HAS_RAY | ST_LEAF_HITS)) | ST_DONE; node = TWK_BVH_SENTINEL; }
-        }
-        else
         {
           // one WIDE node = the four grandchildren of binary node `node` (two levels of the binary tree per round of
           // loads), 64 bytes: child boxes as 8-bit grid coordinates of the node's own box (device_types.h "quantised wide
@@ -551,10 +449,7 @@ traceKernel(LaunchParams p, int depth)
       // instance) or the world-space slots of a flattened instance at the top level. ONE triangle phase serves both:
       // `woop` and `ray.o` always belong to the space the lane is in.
       int triFirst = 0, triLast = -1;
-      // WIDE8: the leaf children of the lane's last node whose boxes were hit; their triangles are fetched one leaf after the other
-      unsigned int leafHits = (WIDE8 && (state & ST_HAS_RAY) && node < 0) ? ((state >> 8) & 0xffu) : 0u;
-      if (WIDE8) { if (leafHits != 0u) { TWK_WAVE_STEP(leafWaveSteps) } }
-      if (!WIDE8 && (state & ST_HAS_RAY) && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
+      if ((state & ST_HAS_RAY) && !((unsigned int) node < (unsigned int) TWK_BVH_SENTINEL))
       {
         TWK_WAVE_STEP(leafWaveSteps)
         if (TWO_LEVEL && node == TWK_BVH_SENTINEL)
@@ -621,23 +516,13 @@ traceKernel(LaunchParams p, int depth)
         res.triangleSlot = closer ? (ts_) : res.triangleSlot;                                                                  \
         if (closer & ((state & ST_ANY_HIT) != 0u))                                                                             \
         {                                                                                                                      \
-          pop = 0u; state = (state & ~(ST_HAS_RAY | ST_LEAF_HITS)) | ST_DONE; triLast = -1; leafHits = 0u;                    \
-          if (WIDE8) node = TWK_BVH_SENTINEL;                                                                                  \
+          pop = 0u; state = (state & ~ST_HAS_RAY) | ST_DONE; triLast = -1;                                                     \
         }                                                                                                                      \
       }
       // (Postponed leaves, slots stored by component, pair fetch, handing a leaf's second triangle to an idle lane: all built,
       // measured and not kept — DESIGN.md 4.1.)
-      for (int ts = triFirst; ; ++ts)
+      for (int ts = triFirst; ts <= triLast; ++ts)
       {
-        if (ts > triLast)
-        {
-          if (!WIDE8 || leafHits == 0u) break;
-          // the next leaf child: its triangles are the slots tgBase + (meta & 31) .. + (meta >> 5)
-          const unsigned int leafSlot = (unsigned int) __ffs((int) leafHits) - 1u;
-          leafHits &= leafHits - 1u;
-          const unsigned int meta = (((leafSlot & 4u) ? metaHi : metaLo) >> (8u * (leafSlot & 3u))) & 0xffu;
-          ts = tgBase + (int) (meta & 31u); triLast = ts + (int) (meta >> 5);
-        }
         const float4* tri = p.triangles + 3 * (size_t) ts;
         const float4 a = tri[0], b = tri[1], c = tri[2];
         if (COUNT) ++triCount;
@@ -656,14 +541,6 @@ traceKernel(LaunchParams p, int depth)
         if (sp == 0) state = (state & ~ST_HAS_RAY) | ST_DONE;
         else { --sp; node = ldsStack[sp * stride]; }
       }
-      if (WIDE8 && (state & ST_HAS_RAY) && node < 0)
-      {
-        // back from the leaf children: on to the node that was chosen in the node step, or done if there was none
-        state &= ~ST_LEAF_HITS;
-        node = ~node;
-        if (node == TWK_BVH_SENTINEL) state = (state & ~ST_HAS_RAY) | ST_DONE;
-      }
-
       TWK_PHASE_END(4)
       if (!(state & ST_HAS_RAY)) node = TWK_BVH_SENTINEL; // what the node loop's condition relies on
       const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
@@ -771,11 +648,11 @@ traceOverflowKernel(LaunchParams p, int depth)
   }
 }
 
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY, bool WIDE8 = false>
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
 static void launchTraceVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
-  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7, PRIMARY, WIDE8>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7, PRIMARY>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
   hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT, PRIMARY>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
 }
 
