@@ -1,12 +1,17 @@
 #!/bin/bash
 # Runs bench.py (no CPU baseline) for each "name[:ENV=VALUE]" argument: name = build/lib_<name>.so variant ("base" = the in-tree library).
+# name wt_<x> = an older tree under build/wt_<x> (git worktree add + make there).
 # usage (GPU box): [STEPS=20 WARMUP=5] bash tools/ab_run.sh base base:TWK_MAX_LEAF=3 k32 ...
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
   [[ "$spec" == *:* ]] && envs=${spec#*:}
   lib=""; [[ "$name" != "base" ]] && lib="TWK_LIB=build/lib_$name.so"
   out=gpurun_out/ab_${spec//[:=]/_}_s${STEPS:-64}.json
+  if [[ "$name" == wt_* ]]; then   # a whole older tree built under build/<name> (git worktree): its own bench.py and library
+    ( cd build/$name && env ${envs//,/ } timeout -k 10 200 python bench.py --no-cpu-baseline --steps ${STEPS:-64} --warmup ${WARMUP:-4} ) > $out 2>/dev/null
+  else
   env $lib ${envs//,/ } timeout -k 10 200 python bench.py --no-cpu-baseline --steps ${STEPS:-64} --warmup ${WARMUP:-4} > $out 2>/dev/null
+  fi
   python - "$spec" "$out" <<'PY'
 import json, sys
 try:

@@ -41,7 +41,7 @@ for path in glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), rec
         used[c] = [len(timed), len(ids)]
 g = lambda c: per.get(c, 0.0)
 res = {
-    "kernel": "twk::traceKernel<false, false, *>",
+    "kernel": a.kernel + "*",
     "steps": a.steps, "warmup": a.warmup, "batch_depth": batch, "resolution": list(a.resolution), "sphere_tess": a.sphere_tess,
     "dispatches_averaged_of_all": used.get("FETCH_SIZE"),
     "fetch_size_kib_per_launch": g("FETCH_SIZE"),
@@ -59,6 +59,10 @@ res = {
     # every vector instruction but fma / mul / add costs on this chip, tools/probes/valu_issue_probe.hip; capped at 1)
     "simd_clocks_per_vector_instruction": (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0) / max(1.0, g("SQ_INSTS_VALU")),
     "valu_issue_utilisation": min(1.0, 4.0 * g("SQ_ACTIVE_INST_VALU") / max(1.0, g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)),
+    # the same without the cap. An ESTIMATE: it prices every SQ_ACTIVE_INST_VALU unit at 4 SIMD clocks; on this chip the plain
+    # fma / mul / add issue in fewer (tools/probes/valu_issue_probe.hip: everything else costs 1.6 x an fma), so the 4-clock model
+    # over-counts and the ratio passes 1 on kernels whose SIMDs issue back to back.
+    "valu_issue_ratio_uncapped_4_clock_model": 4.0 * g("SQ_ACTIVE_INST_VALU") / max(1.0, g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0),
     "valu_lane_utilisation": g("SQ_THREAD_CYCLES_VALU") / max(1.0, 64.0 * g("SQ_ACTIVE_INST_VALU")),
     "lds_bank_conflict_cycles_per_lds_instruction": g("SQ_LDS_BANK_CONFLICT") / max(1.0, g("SQ_INSTS_LDS")),
     "note": f"launches of {batch} iterations (the timed pass of `bench.py --steps {a.steps} --warmup {a.warmup}`); separate --pmc passes for FETCH_SIZE and WRITE_SIZE; counters include Infinity-Cache hits (memory-side of L2)",
