@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--sphere-tess", type=int, default=180,
                     help="N = 1: tessellation of the two spheres of the Cornell scene (`model sphere U U/2`): 180 is the scene file as it stands (64 k triangles, "
                          "cache-resident); 1000 gives 2.0 M and 2800 gives 15.7 M triangles — a scene the caches do not hold, where the HBM roofline applies")
+    ap.add_argument("--native-math", action="store_true",
+                    help="the opt-in approximate build (libtweeker_hip_fast.so: native sin / cos / exp / rcp / sqrt in the shading kernels, the reference's --use_fast_math mode); not bit-identical to the oracle, tests/test_gpu_native_math.py bounds it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-composite-check", action="store_true")
@@ -124,6 +126,8 @@ def main():
     if world != n_gpus:
         n_gpus = world
 
+    if args.native_math:  # before the package is imported: it binds the library it finds in TWK_LIB
+        os.environ["TWK_LIB"] = os.path.join(ROOT, "tweeker_raytracer_amd", "libtweeker_hip_fast.so")
     import numpy as np
     import torch
     import tweeker_raytracer_amd as twk
@@ -280,6 +284,8 @@ def main():
             "launch_width": lw,
             "batch_depth": min(batch, max(1, args.steps)),
             "batch_note": "twk_launch is deferred: up to batch_depth consecutive iterations are rendered as ONE wavefront pass (bit-identical image); batch1_Msamples_per_s is the rate at one pass per iteration",
+            "arithmetic": ("approximate (--native-math: libtweeker_hip_fast.so, the reference's --use_fast_math mode; NOT the bit-identical build, bounded by tests/test_gpu_native_math.py)"
+                           if args.native_math else "exact (bit-identical to the CPU oracle: correctly rounded division / square root, fixed-algorithm sin / cos / exp / atan)"),
             "parallelism": "single GPU" if n_gpus == 1 else f"tile-interleaved pixels over {n_gpus} ranks (8x8 tiles, distribute()), local accumulation, one RCCL gather + one compositor launch at the end",
         },
     }

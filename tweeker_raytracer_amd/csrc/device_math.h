@@ -15,6 +15,20 @@
 #define TWK_HD __host__ __device__ __forceinline__
 #define TWK_D  __device__ __forceinline__
 
+// TWK_NATIVE_MATH=1 — the OPT-IN approximate build (libtweeker_hip_fast.so, csrc/Makefile): the shading kernels take gfx950's
+// native v_sin_f32 / v_cos_f32 / v_exp_f32 here, and their translation unit is compiled with approximate division and square
+// root (v_rcp_f32, v_sqrt_f32), flushed denormals and fused multiply-adds. It is what the reference itself ran: its device code
+// was built with --use_fast_math (apps/rtigo3/CMakeLists.txt:165-184). Images are then no longer bit-identical to the oracle;
+// tests/test_gpu_native_math.py holds them to SURVEY 8(d)'s tolerance (relative RMSE <= 2 %). The default build is exact.
+#ifndef TWK_NATIVE_MATH
+#define TWK_NATIVE_MATH 0
+#endif
+#if TWK_NATIVE_MATH && defined(__HIP_DEVICE_COMPILE__)
+#define TWK_NATIVE_DEVICE 1
+#else
+#define TWK_NATIVE_DEVICE 0
+#endif
+
 namespace twk {
 
 static const float kPi      = 3.14159265358979323846f;  // M_PIf   (vector_math.h)
@@ -46,6 +60,9 @@ TWK_HD float cosKernel(float r)
 
 TWK_HD float sinP(float x)
 {
+#if TWK_NATIVE_DEVICE
+  return __builtin_amdgcn_sinf(x * 0.15915494309189535f); // v_sin_f32 takes revolutions; arguments here lie within a few turns
+#endif
   float sign = 1.0f;
   float ax = x;
   if (x < 0.0f) { sign = -1.0f; ax = -x; }
@@ -59,6 +76,9 @@ TWK_HD float sinP(float x)
 
 TWK_HD float cosP(float x)
 {
+#if TWK_NATIVE_DEVICE
+  return __builtin_amdgcn_cosf(x * 0.15915494309189535f);
+#endif
   float sign = 1.0f;
   const float ax = (x < 0.0f) ? -x : x;
   float r; int j;
@@ -73,6 +93,9 @@ TWK_HD float cosP(float x)
 // --- exp -------------------------------------------------------------------------------------
 TWK_HD float expP(float x)
 {
+#if TWK_NATIVE_DEVICE
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); // v_exp_f32
+#endif
   if (x > 88.0f)  return asFloat(0x7f800000u);
   if (x < -87.0f) return 0.0f;
   float z = floorf(1.44269504088896341f * x + 0.5f);
