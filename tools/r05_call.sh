@@ -1,7 +1,11 @@
 set -e
 mkdir -p gpurun_out
-TWK_LANE_STAGGER=3 python -m pytest tests/test_gpu_pass_variants.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r05j_pytest.log 2>&1 || { tail -40 gpurun_out/r05j_pytest.log; exit 1; }
-tail -2 gpurun_out/r05j_pytest.log
-STEPS=20 WARMUP=5 bash tools/ab_run.sh base base:TWK_PASS_LANES=2 base:TWK_LANE_STAGGER=2 base:TWK_LANE_STAGGER=3 base:TWK_LANE_STAGGER=5 base:TWK_LANE_STAGGER=3,TWK_LANE_TRACE_WAVES=6 base:TWK_LANE_STAGGER=5,TWK_LANE_TRACE_WAVES=6 base base:TWK_LANE_STAGGER=3 base:TWK_LANE_STAGGER=3,TWK_LANE_TRACE_WAVES=6 | tee gpurun_out/r05j_stagger_s20.txt
-STEPS=64 WARMUP=4 bash tools/ab_run.sh base base:TWK_LANE_STAGGER=3 base:TWK_LANE_STAGGER=3,TWK_LANE_TRACE_WAVES=6 base:TWK_LANE_STAGGER=5,TWK_LANE_TRACE_WAVES=6 | tee gpurun_out/r05j_stagger_s64.txt
-STEPS=10 WARMUP=5 bash tools/ab_run.sh base base:TWK_LANE_STAGGER=3 base:TWK_LANE_STAGGER=3,TWK_LANE_TRACE_WAVES=6 base:TWK_LANE_STAGGER=5,TWK_LANE_TRACE_WAVES=6 | tee gpurun_out/r05j_stagger_s10.txt
+for v in 1 0; do
+  export TWK_TREELET_LAYOUT=$v
+  bash tools/pmc_collect.sh r05l/pmc_tess2800_layout$v 32 32 --sphere-tess 2800 > gpurun_out/r05l_pmc_layout$v.log 2>&1
+  python3 tools/pmc_traffic.py gpurun_out/r05l/pmc_tess2800_layout$v gpurun_out/r05l_traffic_tess2800_layout$v.json --sphere-tess 2800 > /dev/null
+  python3 tools/pmc_summarize.py gpurun_out/r05l/pmc_tess2800_layout$v gpurun_out/r05l_counters_tess2800_layout$v.md > /dev/null
+  python3 -c "
+import json; r=json.load(open('gpurun_out/r05l_traffic_tess2800_layout$v.json'))
+print('layout $v', {k: r[k] for k in ('hbm_bytes_per_launch','l2_hit_rate','l2_hits_per_launch','l2_misses_per_launch','wave_cycles_waiting_on_memory','valu_issue_ratio_uncapped_4_clock_model','valu_lane_utilisation')})"
+done
