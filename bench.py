@@ -71,13 +71,13 @@ def self_launch(n_gpus, argv):
     return proc.wait()
 
 
-def pick_pmc_record(steps, batch_depth, resolution, sphere_tess=180):
+def pick_pmc_record(steps, batch_depth, resolution, sphere_tess=180, kernel="trace"):
     """HBM-side bytes come from rocprofv3 --pmc passes (tools/pmc_collect.sh + tools/pmc_traffic.py), which cannot run
     inside this process. A committed record is carried ONLY when it was taken at this run's launch size: same steps,
     same batch depth, same resolution. Newest record (by name) wins. Returns (record, file name) or (None, reason)."""
     import glob
     seen = []
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_trace_hbm_traffic*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kernel}_hbm_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 rec = json.load(f)
@@ -366,6 +366,37 @@ def main():
         scene_bytes = int(bi["nodes"]) * 64 + int(bi["triangleSlots"]) * 48  # what the traversal kernel reads of the scene: its nodes + triangle slots
         cache_resident = scene_bytes < (256 << 20)                           # MI355X_MICROARCH: Infinity Cache 256 MiB (L2 32 MiB aggregate)
         algo_frac_spec = algo_gbps / HBM_SPEC_GBPS
+        # What binds the kernel, decided from what was MEASURED where a PMC record of this launch size exists: the
+        # HBM-side rate against the stream peak of this run, and the issue ratio of the record (an estimate: 4 SIMD clocks per
+        # SQ_ACTIVE_INST_VALU unit; plain fma / mul / add issue in fewer, so it passes 1 on a kernel that issues back to back).
+        issue_ratio = (pmc.get("valu_issue_ratio_uncapped_4_clock_model") or pmc.get("valu_issue_utilisation")) if pmc else None
+        hbm_frac_measured = (hbm_side_gbps / stream_peak) if hbm_side_gbps else None
+        if pmc and hbm_frac_measured is not None and issue_ratio is not None:
+            bound = "hbm" if hbm_frac_measured >= 0.6 and hbm_frac_measured >= 0.7 * min(issue_ratio, 1.0) else ("valu-issue" if issue_ratio >= 0.85 else "memory-latency")
+            bound_source = f"measured: HBM-side {hbm_frac_measured:.2f} of the stream peak, vector issue ratio {issue_ratio:.2f} ({pmc_source})"
+        else:
+            bound = "valu-issue" if cache_resident else "hbm"
+            bound_source = "assumed from the size of the scene (" + ("cache-resident" if cache_resident else "larger than the Infinity Cache") + "): no PMC record at this launch size"
+        # the shade kernel beside it (housekeeping): time, lanes per phase from this run's measurement build, and
+        # its own PMC record when one exists at this launch size
+        spmc, spmc_source = (None, "N > 1") if n_gpus != 1 else pick_pmc_record(args.steps, result["config"]["batch_depth"], (width, height), args.sphere_tess, kernel="shade")
+        sp_ws, sp_ln, sp_cy = st["shadePhaseWaveSteps"], st["shadePhaseLanes"], st["shadePhaseCycles"]
+        phase_names = ["path", "volume_fetch", "miss", "hit_record", "tangent", "texcoord", "light_hit", "sample_lambert", "sample_mirror", "sample_glass", "sample_ggx",
+                       "sample_ggx_glass", "nee_sample", "nee_eval", "radiance_rmw", "tail", "volume_push", "aov", "kernel_load", "kernel_append", "kernel_iteration"]
+        shade_ms, shade_launches = prof["shade"]["ms"], max(1, prof["shade"]["launches"])
+        shade_block = {
+            "kernel": "twk::shadeKernel<ENV, TEX, PRIMARY, LDS_TABLES, MEASURE>",
+            "ms_per_step": shade_ms / args.steps, "launches": shade_launches,
+            "segments_per_step": (st["shadedHits"] + st["missed"]) / args.steps,
+            "bound": "at three limits at once (profiles/r05_shade_diagnosis.md): vector issue (busy ~1.0), the HBM rate of its three big launches, the launch and fetch-chain floors of the small ones",
+            "valu_issue_ratio_4_clock_model_pmc": spmc.get("valu_issue_ratio_uncapped_4_clock_model") if spmc else None,
+            "valu_lane_utilisation_pmc": spmc.get("valu_lane_utilisation") if spmc else None,
+            "hbm_side_gbps_pmc": (spmc["hbm_bytes_per_launch"] / (shade_ms * 1.0e-3 / shade_launches) / 1.0e9) if spmc else None,
+            "pmc_source": spmc_source if spmc else f"null: {spmc_source}",
+            # lane occupancy and share of the kernel's wave time per phase of the shading of a segment (measurement build, this run)
+            "phases": {n: {"lanes_of_64": round(sp_ln[k] / (64.0 * sp_ws[k]), 3), "wave_executions_per_iteration": round(sp_ws[k] / max(1, sp_ws[20]), 3),
+                           "share_of_wave_time": round(sp_cy[k] / max(1, sp_cy[20]), 3)} for k, n in enumerate(phase_names) if sp_ws[k]},
+        }
         # SURVEY 8(d) / task contract: achieved = ALGORITHMIC bytes per launch / average launch duration of the dominant kernel,
         # peak = HBM spec. On a scene that lives in the caches these bytes are served by LDS / L1 / L2, so `frac` can pass 1:
         # it then says "not HBM-bound", nothing more. What does bound the kernel, and the HBM-side bytes, are stated beside it.
@@ -377,10 +408,12 @@ def main():
             # what binds the kernel (VERDICT / ADVICE round 3): on a scene the caches hold it is not HBM — `frac` below stays the
             # contract's algorithmic-bytes fraction and may exceed 1 there (frac_valid says so); frac_of_binding_limit is the
             # fraction of the limit that does bind (vector-issue slots x lanes active per instruction, from the PMC record)
-            "bound": "valu-issue" if cache_resident else "hbm",
+            "bound": bound,
+            "bound_source": bound_source,
             "frac_valid": bool(not cache_resident or algo_frac_spec <= 1.0),
-            "frac_of_binding_limit": ((pmc.get("valu_issue_utilisation") or 0.0) * (pmc.get("valu_lane_utilisation") or 0.0) if (pmc and cache_resident)
-                                      else ((hbm_side_gbps / stream_peak) if hbm_side_gbps else None)),
+            # of the limit that binds: HBM-side rate / stream peak where HBM binds; where vector issue binds, the lanes doing work per
+            # issued vector instruction (the issue slots themselves are full: see issue.valu_issue_ratio_4_clock_model_pmc)
+            "frac_of_binding_limit": ((hbm_side_gbps / stream_peak) if (bound == "hbm" and hbm_side_gbps) else ((pmc.get("valu_lane_utilisation") if pmc else None))),
             "achieved": algo_gbps,
             "peak": HBM_SPEC_GBPS,
             "unit": "GB/s",
@@ -422,6 +455,8 @@ def main():
                        "gather_peak_glaneloads_per_s_measured": gather_peak},
             # vector-instruction issue, from the same PMC passes as `traffic` (null without a matching record)
             "issue": {"valu_issue_utilisation_pmc": pmc.get("valu_issue_utilisation") if pmc else None,
+                      "valu_issue_ratio_4_clock_model_pmc": issue_ratio,
+                      "issue_ratio_note": "SQ_ACTIVE_INST_VALU x 4 clocks / SIMD clocks of the dispatch, uncapped: an estimate (fma / mul / add issue in fewer than 4 clocks, so a kernel issuing back to back reads above 1)",
                       "simd_clocks_per_vector_instruction_pmc": pmc.get("simd_clocks_per_vector_instruction") if pmc else None,
                       "valu_lane_utilisation_pmc": pmc.get("valu_lane_utilisation") if pmc else None,
                       "wave_cycles_waiting_on_memory_pmc": pmc.get("wave_cycles_waiting_on_memory") if pmc else None},
@@ -446,6 +481,7 @@ def main():
                                  enumerate(["refill_ray_fetch", "node_loop", "leaf_or_instance_step", "triangle_loop", "pop_and_result_write"])},
             "Mrays_per_s": rays / trace_s / 1.0e6,
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            "shade": shade_block,
         }
 
     # ---- CPU baseline: the oracle on the host cores, a bounded sample of the same workload -------------

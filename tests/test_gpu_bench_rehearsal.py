@@ -96,7 +96,10 @@ def test_single_gpu_line_carries_the_contract():
         assert key in roof, key
     # the Cornell scene is cache-resident: what binds the traversal kernel there is vector-instruction issue, and the line says so
     # beside the contract's algorithmic-bytes fraction (which may pass 1 on such a scene: frac_valid)
-    assert roof["bound"] == "valu-issue" and roof["scene_cache_resident"] is True and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    # (this run's launch size — 6 steps — has no PMC record under profiles/: the bound is then the one assumed from the scene's size, and says so)
+    assert roof["bound"] == "valu-issue" and roof["bound_source"].startswith("assumed") and roof["scene_cache_resident"] is True and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    shade = roof["shade"]
+    assert shade["ms_per_step"] > 0 and 0.2 < shade["phases"]["nee_eval"]["lanes_of_64"] <= 1.0 and shade["phases"]["kernel_iteration"]["share_of_wave_time"] == 1.0
     assert roof["frac_valid"] == (roof["frac"] <= 1.0)
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1.0e-9 and roof["achieved"] > 0
     assert roof["kernel"].startswith("twk::traceKernel<") and roof["avg_launch_ms"] > 0

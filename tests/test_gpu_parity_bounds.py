@@ -152,3 +152,24 @@ def test_c1_whole_image_at_its_full_size(twk, orc):
     mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
     assert mism == 0, f"{mism} of 262144 pixels differ"
     dev.close()
+
+
+def test_c2_whole_frame_at_its_full_sample_count(twk, orc):
+    """C2 — the configuration BASELINE.json's metric is quoted on: Cornell box 1920x1080, 64 spp, full BSDF set — the WHOLE
+    frame at the full sample count, all 2 073 600 pixels against the oracle (16 host threads: ~133 M samples, about half a minute)."""
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt")
+    assert list(app.info.resolution) == [1920, 1080] and app.info.samplesSqrt ** 2 == 64
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    for it in range(64):
+        dev.render(it)
+    gpu = dev.getOutputBufferHost()
+    dev.close()
+    ref = orc.Oracle(miss=app.info.miss)
+    ref.loadApplication(app)
+    for it in range(64):
+        ref.render(it, threads=16)
+    cpu = ref.getOutputBufferHost()
+    assert gpu.shape == (1080, 1920, 4) and np.isfinite(cpu).all() and cpu[..., :3].mean() > 0.1
+    mism = (_bits(gpu) != _bits(cpu)).any(axis=2).sum()
+    assert mism == 0, f"{mism} of 2073600 pixels differ after 64 iterations, max |diff| {np.abs(gpu - cpu).max()}"

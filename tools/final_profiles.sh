@@ -9,11 +9,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 # PMC passes first: the bench lines below then carry the traffic of THESE kernels
 bash tools/pmc_collect.sh $TAG/pmc_s20 20 5 > $OUT/pmc_s20.log 2>&1
-python3 tools/pmc_traffic.py $OUT/pmc_s20 profiles/r04_trace_hbm_traffic_s20.json > /dev/null && cp profiles/r04_trace_hbm_traffic_s20.json $OUT/
+python3 tools/pmc_traffic.py $OUT/pmc_s20 profiles/r05_trace_hbm_traffic_s20.json > /dev/null && cp profiles/r05_trace_hbm_traffic_s20.json $OUT/
 python3 tools/pmc_summarize.py $OUT/pmc_s20 $OUT/pmc_summary_s20.md > /dev/null
+python3 tools/pmc_traffic.py $OUT/pmc_s20 profiles/r05_shade_hbm_traffic_s20.json --kernel shadeKernel > /dev/null && cp profiles/r05_shade_hbm_traffic_s20.json $OUT/
 bash tools/pmc_collect.sh $TAG/pmc_s64 64 64 > $OUT/pmc_s64.log 2>&1
-python3 tools/pmc_traffic.py $OUT/pmc_s64 profiles/r04_trace_hbm_traffic_s64.json > /dev/null && cp profiles/r04_trace_hbm_traffic_s64.json $OUT/
+python3 tools/pmc_traffic.py $OUT/pmc_s64 profiles/r05_trace_hbm_traffic_s64.json > /dev/null && cp profiles/r05_trace_hbm_traffic_s64.json $OUT/
 python3 tools/pmc_summarize.py $OUT/pmc_s64 $OUT/pmc_summary_s64.md > /dev/null
+python3 tools/pmc_traffic.py $OUT/pmc_s64 profiles/r05_shade_hbm_traffic_s64.json --kernel shadeKernel > /dev/null && cp profiles/r05_shade_hbm_traffic_s64.json $OUT/
 echo "pmc done"
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_s20.json 2> $OUT/bench_s20.err; echo "bench s20 rc $?"
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc $?"

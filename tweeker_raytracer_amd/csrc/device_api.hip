@@ -258,7 +258,7 @@ static void refreshParams(TwkDevice dev)
   p.hasCutout = 0; p.hasAlbedoTexture = 0;
   for (const DevMaterial& m : dev->materials) { if (m.textureCutout != 0) p.hasCutout = 1; if (m.textureAlbedo != 0) p.hasAlbedoTexture = 1; }
   // seven trace blocks per CU where the variant that fits them applies (device_types.h TWK_TRACE_WAVES7)
-  p.traceWaves = (!dev->twoLevel && (!p.hasCutout || TWK_TRACE_WAVES_CUTOUT == TWK_TRACE_WAVES7) && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : (p.hasCutout ? (dev->twoLevel ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES) : TWK_TRACE_WAVES);
+  p.traceWaves = (!dev->twoLevel && (!p.hasCutout || TWK_TRACE_CUTOUT_SEVEN) && dev->totalNodes <= (size_t) TWK_TRACE_WAVES7_MAX_NODES) ? TWK_TRACE_WAVES7 : (p.hasCutout ? (dev->twoLevel ? TWK_TRACE_WAVES_CUTOUT_OTHER : TWK_TRACE_WAVES) : TWK_TRACE_WAVES);
   if (dev->traceWavesForced == TWK_TRACE_WAVES || (dev->traceWavesForced == TWK_TRACE_WAVES7 && !dev->twoLevel)) p.traceWaves = dev->traceWavesForced;
   p.envCDF_U = dev->d_envCDF_U; p.envCDF_V = dev->d_envCDF_V;
   for (int k = 0; k < 2; ++k)

@@ -251,8 +251,8 @@ struct LaunchParams
 // +1.7 % (64 iterations) / +2.7 % (20), C4 geometry +2.0 %, a C5 rank's share +3.7 %. The two-level and cutout variants
 // need 76..91 VGPRs and spill at 72 (C4 instances -11 %, C3 -16 %), and scenes of millions of triangles lose 2-6 % (the
 // smaller cache and stack matter there), so those keep six blocks, a 20-entry stack and 64 cached nodes.
-#ifndef TWK_TRACE_WAVES_CUTOUT
-#define TWK_TRACE_WAVES_CUTOUT 7 // blocks per CU of the flattened build with cutout opacity (round 4: 71-80 VGPRs since the restart behind an ignored candidate reads the ray from its record again; rounds 2-3: 93-95 VGPRs, five blocks). 7: the seven-block build (19-entry stack, 32 cached nodes) for scenes of at most TWK_TRACE_WAVES7_MAX_NODES nodes
+#ifndef TWK_TRACE_CUTOUT_SEVEN
+#define TWK_TRACE_CUTOUT_SEVEN 1 // a switch, not a count: 1 = the flattened build with cutout opacity runs the seven-block form like the one without (71-80 VGPRs since round 4's restart from the ray record; 19-entry stack, 32 cached nodes; scenes of at most TWK_TRACE_WAVES7_MAX_NODES nodes), 0 = TWK_TRACE_WAVES blocks per CU
 #endif
 #ifndef TWK_TRACE_WAVES_CUTOUT_OTHER
 #define TWK_TRACE_WAVES_CUTOUT_OTHER 5 // ... of its PRIMARY and two-level builds (93-94 VGPRs; at six 36-100 bytes of scratch)

@@ -1,5 +1,5 @@
-// Launchers of the persistent traversal kernel (trace_persistent.h) for the 4-ary nodes, the stand-alone query kernel and the
-// entry points of the primary rays.
+// Launchers of the persistent traversal kernel (trace_persistent.h), the kernel that re-traces the rays whose LDS stack
+// overflowed, the stand-alone query kernel and the entry points of the primary rays.
 #include "trace_persistent.h"
 
 namespace twk {
@@ -29,6 +29,90 @@ traceQueryKernel(LaunchParams p, const float* __restrict__ rays, unsigned int nu
       ids[2 * i] = res.instance; ids[2 * i + 1] = res.primitive;
     }
   }
+}
+
+// Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again
+// with the single-ray traversal whose stack continues in HBM. Launched behind every traceKernel; exits at once when
+// the list is empty.
+template<bool COUNT, bool CUTOUT, bool PRIMARY>
+__global__ void __launch_bounds__(TWK_TRACE_BLOCK)
+traceOverflowKernel(LaunchParams p, int depth)
+{
+  __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
+  const unsigned int count = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3];
+  if (count == 0u) return;
+  int* ldsStack = stackStorage + threadIdx.x;
+  int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
+  const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
+  const int q = depth & 1;
+  const bool packed = !CUTOUT && !PRIMARY && p.packedQueue != 0 && depth > 0; // as in traceKernel
+  unsigned int nodeCount = 0, triCount = 0, instCount = 0;
+  for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+  {
+    const unsigned int slot = p.overflowSlots[k];
+    const bool isShadow = !(slot < numClosest);
+    float4 o, d;
+    if (PRIMARY)
+    {
+      const PrimaryRay pr = primaryRay(p, slot);
+      o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, p.sceneEpsilon);
+      d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, pr.active ? RT_DEFAULT_MAX : -1.0f);
+    }
+    else
+    {
+      o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
+      d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+    }
+    const unsigned int packedPixel = __float_as_uint(o.w) & TWK_PACKED_PIXEL_MASK;
+    if (packed && !isShadow) { o.w = p.sceneEpsilon; d.w = RT_DEFAULT_MAX; }
+    float tmin = (PRIMARY && CUTOUT) ? p.hitRecord[slot].x : o.w; // carries the distance of the last ignored cutout candidate, if any
+    const unsigned int rayClock = COUNT ? (unsigned int) __builtin_readcyclecounter() : 0u; // time view: this lane's cycles for the re-trace
+    TraceResult res;
+    for (;;)
+    {
+      traverse<COUNT>(p, v3(o), v3(d), tmin, d.w, isShadow && !CUTOUT, ldsStack, spill, res, nodeCount, triCount, instCount);
+      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY))) break;
+      tmin = res.t;
+    }
+    if (COUNT && p.pathTime != nullptr)
+      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[slot - numClosest] : (PRIMARY ? slot : (packed ? packedPixel : p.rayPixel[q][slot]))], float((unsigned int) __builtin_readcyclecounter() - rayClock));
+    if (!isShadow)
+    {
+      p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
+      p.hitInstance[slot] = res.instance;
+      if (p.firstHit != nullptr && depth == 0)
+      {
+        const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
+        p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
+        p.firstHitInstance[pixel] = res.instance;
+      }
+    }
+    else if (res.instance < 0)
+    {
+      const unsigned int sIdx = slot - numClosest;
+      const unsigned int pixel = p.shadowPixel[sIdx];
+      const float4 c = p.shadowPending[sIdx];
+      float4 r = p.pathRadiance[pixel];
+      r.x += c.x; r.y += c.y; r.z += c.z;
+      p.pathRadiance[pixel] = r;
+    }
+  }
+  if (COUNT)
+  {
+    // the persistent kernel already counted these rays and its partial visits; add the re-trace's visits
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.stats[12], (unsigned long long) count);
+    atomicAdd(&p.stats[2], (unsigned long long) nodeCount);
+    atomicAdd(&p.stats[3], (unsigned long long) triCount);
+    atomicAdd(&p.stats[4], (unsigned long long) instCount);
+  }
+}
+
+template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
+static void launchTraceVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
+{
+  const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
+  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7, PRIMARY>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
+  hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT, PRIMARY>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
 }
 
 template<bool COUNT, bool PRIMARY>

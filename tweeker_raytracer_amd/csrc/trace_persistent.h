@@ -172,7 +172,8 @@ traceKernel(LaunchParams p, int depth)
     ST_DONE       = 4u,  // the ray completed in this round and its result is not yet written
     ST_SHADOW     = 8u,  // slot belongs to the shadow queue
     ST_RETRACE    = 16u, // LDS stack overflow: the ray is re-traced by traceOverflowKernel with the spilling traverse()
-    ST_OVERFLOWED = 32u  // set while the overflowed ray is handed over (nothing is written for it here)
+    ST_OVERFLOWED = 32u, // set while the overflowed ray is handed over (nothing is written for it here)
+    ST_CLOCKED    = 64u  // COUNT builds: rayClock holds the ray's elapsed cycles (stopped in the round it completed in), not its start
   };
   unsigned int state = 0u;
   unsigned int slot = 0;
@@ -183,7 +184,7 @@ traceKernel(LaunchParams p, int depth)
   WoopConstants woop; woop.perm = 0u; woop.Sx = 0.0f; woop.Sy = 0.0f; woop.Sz = 0.0f;
   int currentInstance = -1, sp = 0, node = TWK_BVH_SENTINEL;
   unsigned int guard = 0;
-  unsigned int rayClock = 0; // COUNT, time view: shader clock when this lane took its ray
+  unsigned int rayClock = 0; // COUNT, time view: shader clock when this lane took its ray; once the ray has completed (ST_CLOCKED): the cycles it took
 
   for (;;)
   {
@@ -194,7 +195,10 @@ traceKernel(LaunchParams p, int depth)
     // instead of in nearly every round with one to three (round 4).
     if (state & ST_DONE)
     {
-      state &= ~ST_DONE;
+      // time view: the ray's cycles were stopped in the round it completed in, not here — a finished lane's wait for the rest of
+      // its wave is not the path's time (the reference brackets the trace calls of ONE thread with clock(), raygeneration.cu:169-244)
+      const unsigned int rayCycles = COUNT ? ((state & ST_CLOCKED) ? rayClock : (unsigned int) __builtin_readcyclecounter() - rayClock) : 0u;
+      state &= ~(ST_DONE | ST_CLOCKED);
       const bool isShadow = (state & ST_SHADOW) != 0u;
       if (state & ST_RETRACE)
       {
@@ -230,6 +234,7 @@ traceKernel(LaunchParams p, int depth)
         res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
         setupRay(ray, org, dir);
         woopSetup(dir, woop);
+        if (COUNT) rayClock = (unsigned int) __builtin_readcyclecounter() - rayCycles; // the clock runs on behind the ignored candidate
         currentInstance = -1; sp = 0; node = p.topRoot; guard = 0;
         if (p.topRoot2 != TWK_BVH_SENTINEL) { ldsStack[0] = p.topRoot2; sp = 1; }
         state |= ST_HAS_RAY;
@@ -240,7 +245,7 @@ traceKernel(LaunchParams p, int depth)
         p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
         p.hitInstance[slot] = res.instance;
         if (COUNT) ++closestCount;
-        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : (packed ? (__float_as_uint(p.rayOrg[q][slot].w) & TWK_PACKED_PIXEL_MASK) : p.rayPixel[q][slot])], float((unsigned int) __builtin_readcyclecounter() - rayClock)); // time view: the lane's cycles from taking the ray to its result
+        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : (packed ? (__float_as_uint(p.rayOrg[q][slot].w) & TWK_PACKED_PIXEL_MASK) : p.rayPixel[q][slot])], float(rayCycles)); // time view: the lane's cycles from taking the ray to its completion
         if (p.firstHit != nullptr && depth == 0)
         {
           const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
@@ -251,7 +256,7 @@ traceKernel(LaunchParams p, int depth)
       else
       {
         if (COUNT) ++shadowCount;
-        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[p.shadowPixel[slot - numClosest]], float((unsigned int) __builtin_readcyclecounter() - rayClock));
+        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[p.shadowPixel[slot - numClosest]], float(rayCycles));
         if (res.instance < 0)
         {
           // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)
@@ -541,6 +546,7 @@ traceKernel(LaunchParams p, int depth)
         if (sp == 0) state = (state & ~ST_HAS_RAY) | ST_DONE;
         else { --sp; node = ldsStack[sp * stride]; }
       }
+      if (COUNT) { if ((state & (ST_DONE | ST_CLOCKED)) == ST_DONE) { rayClock = (unsigned int) __builtin_readcyclecounter() - rayClock; state |= ST_CLOCKED; } }
       TWK_PHASE_END(4)
       if (!(state & ST_HAS_RAY)) node = TWK_BVH_SENTINEL; // what the node loop's condition relies on
       const unsigned long long active = __ballot((state & ST_HAS_RAY) != 0u);
@@ -570,90 +576,6 @@ traceKernel(LaunchParams p, int depth)
   }
 #undef TWK_WAVE_STEP
 #undef TWK_PHASE_END
-}
-
-// Rays whose traversal overflowed the LDS stack of the persistent kernel (none on the shipped scenes): traced again
-// with the single-ray traversal whose stack continues in HBM. Launched behind every traceKernel; exits at once when
-// the list is empty.
-template<bool COUNT, bool CUTOUT, bool PRIMARY>
-__global__ void __launch_bounds__(TWK_TRACE_BLOCK)
-traceOverflowKernel(LaunchParams p, int depth)
-{
-  __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
-  const unsigned int count = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3];
-  if (count == 0u) return;
-  int* ldsStack = stackStorage + threadIdx.x;
-  int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
-  const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
-  const int q = depth & 1;
-  const bool packed = !CUTOUT && !PRIMARY && p.packedQueue != 0 && depth > 0; // as in traceKernel
-  unsigned int nodeCount = 0, triCount = 0, instCount = 0;
-  for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
-  {
-    const unsigned int slot = p.overflowSlots[k];
-    const bool isShadow = !(slot < numClosest);
-    float4 o, d;
-    if (PRIMARY)
-    {
-      const PrimaryRay pr = primaryRay(p, slot);
-      o = make_float4(pr.origin.x, pr.origin.y, pr.origin.z, p.sceneEpsilon);
-      d = make_float4(pr.direction.x, pr.direction.y, pr.direction.z, pr.active ? RT_DEFAULT_MAX : -1.0f);
-    }
-    else
-    {
-      o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
-      d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
-    }
-    const unsigned int packedPixel = __float_as_uint(o.w) & TWK_PACKED_PIXEL_MASK;
-    if (packed && !isShadow) { o.w = p.sceneEpsilon; d.w = RT_DEFAULT_MAX; }
-    float tmin = (PRIMARY && CUTOUT) ? p.hitRecord[slot].x : o.w; // carries the distance of the last ignored cutout candidate, if any
-    const unsigned int rayClock = COUNT ? (unsigned int) __builtin_readcyclecounter() : 0u; // time view: this lane's cycles for the re-trace
-    TraceResult res;
-    for (;;)
-    {
-      traverse<COUNT>(p, v3(o), v3(d), tmin, d.w, isShadow && !CUTOUT, ldsStack, spill, res, nodeCount, triCount, instCount);
-      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY))) break;
-      tmin = res.t;
-    }
-    if (COUNT && p.pathTime != nullptr)
-      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[slot - numClosest] : (PRIMARY ? slot : (packed ? packedPixel : p.rayPixel[q][slot]))], float((unsigned int) __builtin_readcyclecounter() - rayClock));
-    if (!isShadow)
-    {
-      p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
-      p.hitInstance[slot] = res.instance;
-      if (p.firstHit != nullptr && depth == 0)
-      {
-        const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
-        p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
-        p.firstHitInstance[pixel] = res.instance;
-      }
-    }
-    else if (res.instance < 0)
-    {
-      const unsigned int sIdx = slot - numClosest;
-      const unsigned int pixel = p.shadowPixel[sIdx];
-      const float4 c = p.shadowPending[sIdx];
-      float4 r = p.pathRadiance[pixel];
-      r.x += c.x; r.y += c.y; r.z += c.z;
-      p.pathRadiance[pixel] = r;
-    }
-  }
-  if (COUNT)
-  {
-    // the persistent kernel already counted these rays and its partial visits; add the re-trace's visits
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.stats[12], (unsigned long long) count);
-    atomicAdd(&p.stats[2], (unsigned long long) nodeCount);
-    atomicAdd(&p.stats[3], (unsigned long long) triCount);
-    atomicAdd(&p.stats[4], (unsigned long long) instCount);
-  }
-}
-
-template<bool COUNT, bool CUTOUT, bool TWO_LEVEL, bool W7, bool PRIMARY>
-static void launchTraceVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
-{
-  const int overflowBlocks = gridBlocks < 64 ? gridBlocks : 64; // lanes index the same per-lane spill segments
-  hipLaunchKernelGGL((traceKernel<COUNT, CUTOUT, TWO_LEVEL, W7, PRIMARY>), dim3(gridBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
-  hipLaunchKernelGGL((traceOverflowKernel<COUNT, CUTOUT, PRIMARY>), dim3(overflowBlocks), dim3(TWK_TRACE_BLOCK), 0, stream, p, depth);
 }
 
 } // namespace twk
