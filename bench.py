@@ -372,7 +372,9 @@ def main():
         issue_ratio = (pmc.get("valu_issue_ratio_uncapped_4_clock_model") or pmc.get("valu_issue_utilisation")) if pmc else None
         hbm_frac_measured = (hbm_side_gbps / stream_peak) if hbm_side_gbps else None
         if pmc and hbm_frac_measured is not None and issue_ratio is not None:
-            bound = "hbm" if hbm_frac_measured >= 0.6 and hbm_frac_measured >= 0.7 * min(issue_ratio, 1.0) else ("valu-issue" if issue_ratio >= 0.85 else "memory-latency")
+            # vector issue where the SIMDs issue back to back; else HBM where it carries at least half of what a stream copy moves (the
+            # gathers of a scene the caches do not hold: bandwidth AND latency of HBM); else the latency of cached gathers
+            bound = "valu-issue" if issue_ratio >= 0.85 else ("hbm" if hbm_frac_measured >= 0.5 else "memory-latency")
             bound_source = f"measured: HBM-side {hbm_frac_measured:.2f} of the stream peak, vector issue ratio {issue_ratio:.2f} ({pmc_source})"
         else:
             bound = "valu-issue" if cache_resident else "hbm"

@@ -2,7 +2,7 @@
 # Copies what tools/final_profiles.sh <tag> left under gpurun_out/<tag>/ into profiles/<tag>_* (the tracked summaries).
 # usage (here, after the gpurun call): bash tools/copy_final_profiles.sh <tag>
 set -e
-TAG=${1:-r04z}; SRC=gpurun_out/$TAG; DST=profiles
+TAG=${1:-r05z}; SRC=gpurun_out/$TAG; DST=profiles
 for n in s20 default; do
   cp $SRC/bench_$n.json $DST/${TAG}_bench_$n.json
   cp $SRC/bench_${n}_profiled.json $DST/${TAG}_bench_${n}_profiled.json
@@ -16,5 +16,5 @@ cp $SRC/depth_profile_b64.jsonl $DST/${TAG}_depth_profile_b64.jsonl
 cp $SRC/depth_profile_b20.jsonl $DST/${TAG}_depth_profile_b20.jsonl
 cp $SRC/big_scene_probe.jsonl $DST/${TAG}_big_scene_probe.jsonl
 for n in s20 default; do t=$(find $SRC/stats_$n -name "*kernel_trace.csv" | head -1); python3 tools/step_timeline.py $t > $DST/${TAG}_pass_timeline_$n.txt; done
-cp $SRC/r04_trace_hbm_traffic_s20.json $SRC/r04_trace_hbm_traffic_s64.json $DST/
+cp $SRC/r05_trace_hbm_traffic_s20.json $SRC/r05_trace_hbm_traffic_s64.json $SRC/r05_shade_hbm_traffic_s20.json $SRC/r05_shade_hbm_traffic_s64.json $DST/
 ls $DST | grep ${TAG}_
