@@ -1,5 +1,7 @@
 set -e
 mkdir -p gpurun_out
-python tools/shade_phase_profile.py 20 > gpurun_out/r05n_phases_exact.txt
-TWK_LIB=build/lib_fast.so python tools/shade_phase_profile.py 20 > gpurun_out/r05n_phases_native.txt
-paste -d'\n' gpurun_out/r05n_phases_exact.txt gpurun_out/r05n_phases_native.txt | cut -c1-120
+python -m pytest tests/test_gpu_pass_variants.py tests/test_gpu_parity.py tests/test_gpu_time_view.py -m gpu -x -q > gpurun_out/r05p_pytest.log 2>&1 || { tail -40 gpurun_out/r05p_pytest.log; exit 1; }
+tail -2 gpurun_out/r05p_pytest.log
+STEPS=20 WARMUP=5 bash tools/ab_run.sh base before base before base before | tee gpurun_out/r05p_early_exit_s20.txt
+STEPS=64 WARMUP=4 bash tools/ab_run.sh base before base before | tee gpurun_out/r05p_early_exit_s64.txt
+STEPS=4 WARMUP=4 bash tools/ab_run.sh base before base before | tee gpurun_out/r05p_early_exit_s4.txt

@@ -147,6 +147,17 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
   // of iteration i + 1, so no third barrier per iteration is needed.
+  // The grid is sized for the pass's path count (the host does not know a queue's length): at the deep bounces most blocks have no
+  // window. They leave HERE, before the table copy and its barrier — each used to hold a block slot for a global round trip: with 28 k
+  // of 32 k blocks idle (1 M rays) that was half of the launch (round 5). The block's first window is requested at once, so that
+  // its streams fly while the tables are copied.
+  const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
+  if (blockIdx.x * blockDim.x >= numRays) return;
+  const int q = depth & 1, qn = q ^ 1;
+  const bool packedIn = p.packedQueue != 0 && depth > 0, packedOut = p.packedQueue != 0; // queue 0 is computed (PRIMARY) or written by generateKernel
+  ShadeInput in;
+  loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
+
   __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
   __shared__ unsigned int blockBase[2][2];
   __shared__ unsigned int phaseWords[MEASURE ? 3 * TWK_SHADE_PHASES : 1];
@@ -176,8 +187,6 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     tables.lights    = reinterpret_cast<const DevLight*>(tableStorage + nI + nM);
     __syncthreads();
   }
-  const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
-  const int q = depth & 1, qn = q ^ 1;
   unsigned int* nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + 0];
   unsigned int* shadowCount = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 1];
   unsigned int statHit = 0, statMiss = 0;
@@ -188,9 +197,6 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   // The kernel is bound by its chain of dependent fetches, not by arithmetic, so the chain is kept
   // short: the streams of the NEXT iteration's slot are requested between the two barriers of the append — they fly
   // while the block waits for its returning atomic — and nothing waits for the appended records to be written.
-  const bool packedIn = p.packedQueue != 0 && depth > 0, packedOut = p.packedQueue != 0; // queue 0 is computed (PRIMARY) or written by generateKernel
-  ShadeInput in;
-  loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
   unsigned int buffer = 0u;
 
   // block-uniform trip count: every thread reaches both barriers of every iteration
