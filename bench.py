@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-composite-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the oracle sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a share of 16 cores)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="with --gpus 1: go through the N > 1 path — process group on RCCL, tile distribution, gather, compositor, MAX all-reduce, composite check — with a world of ONE rank (the only way to execute the RCCL branch on a one-GPU box)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 path on ONE GPU: all ranks share device 0, the gather goes over gloo through host memory")
     args = ap.parse_args()
@@ -133,9 +135,20 @@ def main():
     import tweeker_raytracer_amd as twk
 
     dist = None
+    multi = n_gpus > 1 or args.rehearse_rccl  # the exchange path (a world of one rank with --rehearse-rccl)
+    if args.rehearse_rccl and "WORLD_SIZE" not in os.environ:
+        os.environ.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", "29531")})
     if args.rehearse_gloo:
         local_rank = 0
-    if n_gpus > 1:
+    # ONE JSON line on stdout: RCCL prints a version banner to file descriptor 1 when its communicator comes up (found by the
+    # one-rank rehearsal, round 5). In the N > 1 path everything this process or its libraries print goes to stderr; the
+    # result line is written to the saved descriptor at the end.
+    result_fd = None
+    if multi:
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
+    if multi:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if args.rehearse_gloo:
@@ -144,7 +157,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     device = torch.device("cuda", local_rank)
-    c5 = (n_gpus > 1 and not args.weak) or (n_gpus == 1 and args.c5)
+    c5 = (multi and not args.weak) or (n_gpus == 1 and args.c5)
     system = args.system or os.path.join(ROOT, "scenes", "system_rtigo3_cornell_box_c5.txt" if c5 else "system_rtigo3_cornell_box.txt")
     if args.sphere_tess != 180:
         scene_text = open(args.scene).read().replace("sphere 180 90", f"sphere {args.sphere_tess} {args.sphere_tess // 2}")
@@ -158,7 +171,7 @@ def main():
     width, height = info.resolution[0], info.resolution[1]
 
     dev = twk.Device(ordinal=local_rank, index=rank, count=n_gpus, miss=info.miss)
-    app.initDevice(dev, distribution=1 if n_gpus > 1 else 0)
+    app.initDevice(dev, distribution=1 if multi else 0)
     batch = max(1, min(64, args.batch))
     dev.setLaunchBatch(batch)
     # path streams for the largest pass the timed loop will issue: allocated here, not inside the timed region
@@ -169,7 +182,7 @@ def main():
     accum = torch.zeros((height, lw, 4), dtype=torch.float32, device=device)
     dev.setOutputDevicePointer(accum.data_ptr(), accum.numel() * 4)
     gathered = composed = None
-    if n_gpus > 1 and rank == 0:
+    if multi and rank == 0:
         gathered = torch.empty((n_gpus, height, lw, 4), dtype=torch.float32, device=device)
         composed = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
 
@@ -319,9 +332,11 @@ def main():
         result["config"]["crc32_single_device"] = composite["crc_single"]
     if args.rehearse_gloo:
         result["config"]["rehearsal"] = "gloo, all ranks on GPU 0 — NOT a scaling measurement"
+    if args.rehearse_rccl:
+        result["config"]["rehearsal"] = "RCCL with a world of one rank: the N > 1 path's calls on the real backend — NOT a scaling measurement"
 
     # ---- one pass per iteration (what a caller that synchronises after every launch gets, DeviceSingleGPU.cpp:147)
-    if rank == 0 and n_gpus == 1 and not args.no_roofline:
+    if rank == 0 and n_gpus == 1 and not multi and not args.no_roofline:
         dev.setLaunchBatch(1)
         k1 = max(2, min(args.steps, 16))
         for it in range(2):
@@ -487,7 +502,7 @@ def main():
         }
 
     # ---- CPU baseline: the oracle on the host cores, a bounded sample of the same workload -------------
-    if not args.no_cpu_baseline and rank == 0 and n_gpus == 1:
+    if not args.no_cpu_baseline and rank == 0 and n_gpus == 1 and not multi:
         from oracle import orc
         ref = orc.Oracle(miss=info.miss)
         ref.loadApplication(app)
@@ -577,7 +592,10 @@ def main():
             result["cpu_baseline"]["same_kernels_one_core"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        if result_fd is not None:
+            os.write(result_fd, (json.dumps(result) + "\n").encode())
+        else:
+            print(json.dumps(result), flush=True)
     dev.close()
     if dist is not None:
         dist.barrier()

@@ -107,3 +107,26 @@ def test_single_gpu_line_carries_the_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["sample_bit_identical_to_gpu"] is True
+
+
+def test_rccl_branch_with_a_world_of_one_rank():
+    """The RCCL branch of the exchange step — process group on the nccl backend, dist.gather of the device tensor into rank 0's
+    list of views, the compositor launch, the MAX all-reduce and the barriers — cannot run with two ranks on one GPU (RCCL
+    refuses a device twice). `--rehearse-rccl` executes it with a world of ONE rank: every call of the N > 1 path on the real
+    backend, the composed frame equal to the plain single-device render."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(key, None)
+    env["MASTER_PORT"] = str(29700 + (os.getpid() % 200))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "4", "--rehearse-rccl"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"ONE JSON line on stdout (RCCL's version banner belongs on stderr): {lines[:6]}"
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 1 and cfg["resolution"] == [3840, 2160] and cfg["launch_width"] == 3840
+    assert cfg["composite_bit_identical_to_single_device"] is True and cfg["crc32_composed"] == cfg["crc32_single_device"]
+    assert cfg["gather_plus_compositor_ms"] > 0 and cfg["closing_barrier_ms"] >= 0
+    assert cfg["collective"] == "one gather to rank 0" and cfg["rehearsal"].startswith("RCCL with a world of one rank")
