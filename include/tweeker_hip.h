@@ -440,6 +440,8 @@ typedef struct TwkAppInfo
   float center[3], phi, theta, fov, distance;
   int   numCameras, numLights, numMaterials, numGeometries, numInstances;
   int   shaderVariant; /* "shaderVariant" of the system description (grammar extension): TWK_SHADERS_*; applied by twk_app_init_device */
+  int   nextEventEstimation; /* ABI 9: "nextEventEstimation 0|1" (grammar extension ≙ USE_NEXT_EVENT_ESTIMATION), default 1; applied by twk_app_init_device */
+  int   debugExceptions;     /* ABI 9: "debugExceptions 0|1" (grammar extension ≙ USE_DEBUG_EXCEPTIONS), default 0 */
 } TwkAppInfo;
 
 int twk_app_info(TwkApp app, TwkAppInfo* info);

@@ -36,6 +36,7 @@ class Oracle:
     def __init__(self, index=0, count=1, miss=1, libm=False, nee=True, debugExceptions=False):
         assert not (libm and (not nee or debugExceptions)) and not (not nee and debugExceptions), "one compile-time switch per oracle build"
         self.lib = _load(ORACLE_LIBM_PATH if libm else (ORACLE_NEE0_PATH if not nee else (ORACLE_DBGEXC_PATH if debugExceptions else ORACLE_PATH)))
+        self.nee, self.debugExceptions = bool(nee), bool(debugExceptions)
         self.lib.orc_last_error.restype = C.c_char_p
         self._h = C.c_void_p()
         self._chk(self.lib.orc_create(C.byref(self._h), int(index), int(count), int(miss)))
@@ -114,6 +115,10 @@ class Oracle:
         """Feed the scene an Application parsed (same inputs twk_app_init_device hands to the HIP device)."""
         st = state if state is not None else app.state
         self.setShaderVariant(getattr(app.info, "shaderVariant", 0))
+        # the reference's config.h switches are compile-time here as there: this object must be the build the description asks for
+        # (a description that leaves the defaults may still be rendered by another build: the caller flipped the device's switch itself)
+        assert (bool(getattr(app.info, "nextEventEstimation", 1)) or not self.nee) and (not getattr(app.info, "debugExceptions", 0) or self.debugExceptions), \
+            "the description's nextEventEstimation 0 / debugExceptions 1 need orc.Oracle(nee=False) / orc.Oracle(debugExceptions=True)"
         if distribution is not None:
             st.distribution = int(distribution)
         self.setState(st)

@@ -134,3 +134,24 @@ def test_nee_on_and_off_converge_to_the_same_image(twk):
     assert R < 1.6, "block means of the NEE and the brute-force image differ by more than their noise"
     assert abs(bias) < 0.003
     assert cross < 1.1 * np.sqrt((floor_on ** 2 + floor_off ** 2) / 4), "per-pixel RMSE between the two images exceeds what their noise floors explain"
+
+
+def test_switch_from_the_system_description(twk, orc):
+    """`nextEventEstimation 0` in the system description (grammar extension) reaches the device through twk_app_init_device: the
+    image equals the brute-force oracle's, and the description of a scene without the key renders with NEE as before."""
+    from conftest import scene_path
+    system = open(scene_path("system_rtigo3_cornell_box.txt")).read() + "nextEventEstimation 0\n"
+    app = twk.Application(system_text=system, scene_text=open(scene_path("scene_rtigo3_cornell_box.txt")).read())
+    app.setResolution(96, 54)
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    ref = orc.Oracle(miss=app.info.miss, nee=False)
+    ref.loadApplication(app)
+    for it in range(3):
+        dev.render(it)
+        ref.render(it, threads=8)
+    gpu, cpu = dev.getOutputBufferHost(), ref.getOutputBufferHost()
+    dev.close()
+    assert (_bits(gpu) != _bits(cpu)).any(axis=2).sum() == 0
+    with pytest.raises(AssertionError):
+        orc.Oracle(miss=app.info.miss).loadApplication(app)  # the NEE build of the oracle is not what this description asks for

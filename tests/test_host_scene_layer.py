@@ -142,3 +142,20 @@ def test_system_description_round_trip(twk):
     # defaults: no envMap line, neutral tonemapper
     text = twk.Application(system_text="", scene_text=scene).systemDescription()
     assert "envMap" not in text and text.splitlines()[0] == "strategy 0" and "gamma 1\n" in text and text.endswith("brightness 1\n")
+
+
+def test_config_switches_as_description_keys(twk):
+    """Grammar extensions for the reference's compile-time switches (shaders/config.h:50-56): `nextEventEstimation 0|1` (default 1)
+    and `debugExceptions 0|1` (default 0); written back only when they differ from the defaults, so a reference file round-trips
+    unchanged."""
+    from conftest import scene_path
+    scene = open(scene_path("scene_rtigo3_cornell_box_c1.txt")).read()
+    plain = twk.Application(system_text="resolution 64 64\n", scene_text=scene)
+    assert plain.info.nextEventEstimation == 1 and plain.info.debugExceptions == 0
+    assert "nextEventEstimation" not in plain.systemDescription() and "debugExceptions" not in plain.systemDescription()
+    app = twk.Application(system_text="resolution 64 64\nnextEventEstimation 0\ndebugExceptions 1\n", scene_text=scene)
+    assert app.info.nextEventEstimation == 0 and app.info.debugExceptions == 1
+    text = app.systemDescription()
+    assert "nextEventEstimation 0\n" in text and "debugExceptions 1\n" in text
+    again = twk.Application(system_text=text, scene_text=scene)
+    assert again.info.nextEventEstimation == 0 and again.info.debugExceptions == 1

@@ -94,7 +94,7 @@ class AppInfo(C.Structure):
                 ("clockFactor", C.c_float), ("center", f3), ("phi", C.c_float), ("theta", C.c_float),
                 ("fov", C.c_float), ("distance", C.c_float), ("numCameras", C.c_int), ("numLights", C.c_int),
                 ("numMaterials", C.c_int), ("numGeometries", C.c_int), ("numInstances", C.c_int),
-                ("shaderVariant", C.c_int)]
+                ("shaderVariant", C.c_int), ("nextEventEstimation", C.c_int), ("debugExceptions", C.c_int)]
 
 
 # Every symbol include/tweeker_hip.h declares; tests/test_cabi_symbols.py checks header == this list == the .so.

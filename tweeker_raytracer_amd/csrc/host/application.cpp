@@ -100,6 +100,10 @@ bool Application::loadSystemDescription(const std::string& text, std::string& er
     // Extension of the grammar (not in the reference): which app's closest-hit rule for light hits the scene was authored
     // for — 0 rtigo3, 1 Optix7Gui (intro_07's app ends a path on a light's back face, closesthit.cu:189-226).
     else if (key == "shaderVariant") { ok = readInt(parser, i[0]); if (ok) shaderVariant = (i[0] == 1) ? 1 : 0; }
+    // Extensions of the grammar for the reference's two compile-time switches of shaders/config.h:50-56, which a system
+    // description cannot reach there (they need a rebuild): USE_NEXT_EVENT_ESTIMATION and USE_DEBUG_EXCEPTIONS.
+    else if (key == "nextEventEstimation") { ok = readInt(parser, i[0]); if (ok) nextEventEstimation = (i[0] != 0) ? 1 : 0; }
+    else if (key == "debugExceptions")     { ok = readInt(parser, i[0]); if (ok) debugExceptions = (i[0] != 0) ? 1 : 0; }
     // tonemapper settings (Application.cpp:1244-1292), consumed by twk_tonemap / screenshot
     else if (key == "gamma")          { ok = readFloat(parser, tonemapper.gamma); }
     else if (key == "whitePoint")     { ok = readFloat(parser, tonemapper.whitePoint); }
@@ -144,6 +148,8 @@ std::string Application::systemDescription() const
   d << "epsilonFactor " << epsilonFactor << std::endl;
   d << "lensShader " << lensShader << std::endl;
   if (shaderVariant != 0) d << "shaderVariant " << shaderVariant << std::endl;
+  if (nextEventEstimation != 1) d << "nextEventEstimation " << nextEventEstimation << std::endl;
+  if (debugExceptions != 0) d << "debugExceptions " << debugExceptions << std::endl;
   d << "center " << camera.center[0] << " " << camera.center[1] << " " << camera.center[2] << std::endl;
   d << "camera " << camera.phi << " " << camera.theta << " " << camera.fov << " " << camera.distance << std::endl;
   if (!prefixScreenshot.empty()) d << "prefixScreenshot " << prefixScreenshot << std::endl;

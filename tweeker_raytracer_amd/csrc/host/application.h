@@ -81,6 +81,8 @@ public:
   int   light         = 0;
   int   miss          = 1;
   int   lensShader    = 0;
+  int   nextEventEstimation = 1; // grammar extension "nextEventEstimation": ≙ USE_NEXT_EVENT_ESTIMATION (shaders/config.h:50-52)
+  int   debugExceptions = 0;     // grammar extension "debugExceptions": ≙ USE_DEBUG_EXCEPTIONS (config.h:54-56)
   int   shaderVariant = 0; // grammar extension "shaderVariant": 0 rtigo3, 1 Optix7Gui light-hit rule (include/tweeker_hip.h TWK_SHADERS_*)
   int   samplesSqrt   = 1;
   int   resolution[2] = {1, 1};

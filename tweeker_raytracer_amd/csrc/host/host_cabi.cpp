@@ -82,7 +82,7 @@ try
   info->phi = a.camera.phi; info->theta = a.camera.theta; info->fov = a.camera.fov; info->distance = a.camera.distance;
   info->numCameras = (int) a.cameras.size(); info->numLights = (int) a.lights.size(); info->numMaterials = (int) a.materials.size();
   info->numGeometries = (int) a.geometries.size(); info->numInstances = (int) a.instances.size();
-  info->shaderVariant = a.shaderVariant;
+  info->shaderVariant = a.shaderVariant; info->nextEventEstimation = a.nextEventEstimation; info->debugExceptions = a.debugExceptions;
   return TWK_SUCCESS;
 }
 TWK_CATCH("twk_app_info")
@@ -176,6 +176,8 @@ try
   TwkDeviceState state = a.deviceState();
   if ((rc = twk_set_state(dev, &state))) return rc;
   if ((rc = twk_set_shader_variant(dev, a.shaderVariant))) return rc;
+  if ((rc = twk_set_next_event_estimation(dev, a.nextEventEstimation))) return rc;
+  if ((rc = twk_set_debug_exceptions(dev, a.debugExceptions))) return rc;
   if ((rc = twk_init_cameras(dev, a.cameras.data(), (int) a.cameras.size()))) return rc;
   if ((rc = twk_init_lights(dev, a.lights.data(), (int) a.lights.size()))) return rc;
   if ((rc = twk_init_materials(dev, a.materials.data(), (int) a.materials.size()))) return rc;
