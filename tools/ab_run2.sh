@@ -1,6 +1,6 @@
 #!/bin/bash
 # Like ab_run.sh, at the driver's launch size too: for each "name[:ENV=VALUE,...]" prints the 20-step and the 64-step line.
-# usage (GPU box): bash tools/ab_run2.sh base sq8 base:TWK_WIDE8=1 ...
+# usage (GPU box): bash tools/ab_run2.sh base sq8 base:TWK_PACKED_QUEUE=0 ...
 for spec in "$@"; do
   name=${spec%%:*}; envs=""
   [[ "$spec" == *:* ]] && envs=${spec#*:}

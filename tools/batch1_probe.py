@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rate at ONE wavefront pass per iteration (what a caller that synchronises after every launch gets), with and without
-the tail kernel (TWK_TAIL_DEPTH). usage (GPU box): TWK_TAIL_DEPTH=3 python tools/batch1_probe.py [batch ...]"""
+the tail kernel of tools/experiments/r04_tail_kernel.patch, TWK_TAIL_DEPTH, where that patch is applied). usage (GPU box): python tools/batch1_probe.py [batch ...]"""
 import json
 import os
 import sys

@@ -1,7 +1,8 @@
 set -e
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_bench_rehearsal.py -m gpu -x -q > gpurun_out/r05q_pytest.log 2>&1 || { tail -60 gpurun_out/r05q_pytest.log; exit 1; }
-tail -3 gpurun_out/r05q_pytest.log
-python bench.py --gpus 1 --steps 20 --warmup 5 --rehearse-rccl > gpurun_out/r05q_bench_rehearse_rccl.json 2> gpurun_out/r05q_bench_rehearse_rccl.err
+python -m pytest tests -m gpu -x -q > gpurun_out/r05final_pytest.log 2>&1 || { tail -40 gpurun_out/r05final_pytest.log; exit 1; }
+tail -2 gpurun_out/r05final_pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05final_bench_s20.json
 python -c "
-import json; r=json.load(open('gpurun_out/r05q_bench_rehearse_rccl.json')); print(r['value'], r['config']['collective'], r['config']['gather_plus_compositor_ms'], r['config']['closing_barrier_ms'], r['config']['composite_bit_identical_to_single_device'], r.get('single_device_same_frame_Msamples_per_s'))"
+import json; r=json.load(open('gpurun_out/r05final_bench_s20.json')); print(r['value'], r['roofline']['bound'], round(r['roofline']['frac'],3), r['roofline']['kernel_ms_per_step'], r['cpu_baseline']['sample_bit_identical_to_gpu'])"
