@@ -203,7 +203,6 @@ struct LaunchParams
   float4* aovAlbedo;      // their running means per launch index (raygeneration.cu:239-262)
   float4* aovNormal;
   int     shaderVariant;  // TWK_SHADERS_RTIGO3 / TWK_SHADERS_OPTIX7GUI (include/tweeker_hip.h)
-  int     shadeSort;      // 1: shadeKernel shades the slots of a block's window in class order (shade_kernels.hip "class-coherent execution"); TWK_SHADE_SORT=0: slot order
   int     nextEventEstimation; // ≙ USE_NEXT_EVENT_ESTIMATION (shaders/config.h:50-52), a run-time switch here (twk_set_next_event_estimation): 0 = brute-force path tracing, no light sampling, no MIS weights
   int     debugExceptions;     // ≙ USE_DEBUG_EXCEPTIONS (config.h:54-56; raygeneration.cu:205-218): NaN / Inf / negative samples become super red / green / blue instead of NaN being dropped
   int     outputFrame;    // 1: `output` is a shared full W x H frame addressed by absolute pixel (ZeroCopy / PeerAccess strategies), 0: this device's packed launchWidth x H buffer
@@ -233,8 +232,6 @@ struct LaunchParams
 // Counter block layout (unsigned int each), zeroed once per launch.
 // per depth d (0..maxDepth): [d*4+0] rays in queue d, [d*4+1] shadow rays emitted by shade d,
 // [d*4+2] chunk tickets of trace launch d (second half of a long queue), [d*4+3] rays of trace launch d that overflowed the LDS stack
-// (Round 5 tried the two queue lengths a block appends to as ONE 8-byte word and one 64-bit returning atomic per block iteration:
-// no faster without the class sort, 5 % slower with it — profiles/r05_shade_experiments.md.)
 #define TWK_COUNTERS_PER_DEPTH 4
 #define TWK_MAX_DEPTH 64
 

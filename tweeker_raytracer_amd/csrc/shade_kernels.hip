@@ -73,9 +73,8 @@ static_assert(TWK_FLAG_DIFFUSE == (1u << 2) && TWK_FLAG_ALBEDO == (1u << 28) && 
 
 // PRIMARY ("primary rays" below): queue 0 was never written; the slot's ray and path state are computed.
 // packed: the queue was written by shadeKernel in the packed form (device_types.h LaunchParams::packedQueue).
-// knownInstance: the slot's hit instance was read before (the class sort below hands it over through LDS); else it is fetched.
-template<bool PRIMARY, bool KNOWN_INSTANCE = false>
-TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsigned int numRays, bool packed, ShadeInput& in, int knownInstance = -1)
+template<bool PRIMARY>
+TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsigned int numRays, bool packed, ShadeInput& in)
 {
   in.inRange = slot < numRays;
   if (PRIMARY)
@@ -87,7 +86,7 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
       in.rd = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.active ? RT_DEFAULT_MAX : -1.0f);
       in.pixel = slot;
       in.hit = p.hitRecord[slot];
-      in.instanceIndex = KNOWN_INSTANCE ? knownInstance : p.hitInstance[slot];
+      in.instanceIndex = p.hitInstance[slot];
       in.throughputPdf = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
       // a scene with cutout opacity: the first traversal stored the seed in queue 0 and its opacity tests drew from it
       in.seedFlags = p.hasCutout ? p.raySeedFlags[0][slot] : make_uint2(ray.seed, 0u);
@@ -99,7 +98,7 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
     in.ro = p.rayOrg[q][slot];
     in.rd = p.rayDir[q][slot];
     in.hit = p.hitRecord[slot];
-    in.instanceIndex = KNOWN_INSTANCE ? knownInstance : p.hitInstance[slot];
+    in.instanceIndex = p.hitInstance[slot];
     in.throughputPdf = p.rayThroughput[q][slot];
     if (packed)
     {
@@ -119,72 +118,6 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
 // Block barrier that orders LDS only. __syncthreads() also drains the wave's outstanding global loads and stores
 // (s_waitcnt vmcnt(0)), which is exactly what the two barriers of the append must not do: see shadeKernel.
 TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// ---------------------------------------------------------------------------------------------
-// Class-coherent execution (round 5). The shading of a segment branches on what was hit — nothing, a light, one of five BSDFs —
-// and a wave pays for every branch any of its lanes takes: on C2 the GGX wall's tangent frame, sample and eval ran in 53 % of the
-// wave iterations with 20 % of the lanes (profiles/r05a_shade_phases_c2_b20.txt) and the kernel is bound by vector-instruction
-// issue (profiles/r05a_shade_fma_sensitivity.txt: every added v_fma costs 0.7 of a full issue slot from the first one on).
-// So the block sorts its window of TWK_SHADE_BLOCK queue slots by class before it shades them: thread t shades slot
-// window + perm[t], where perm is a counting sort through LDS — per wave one ballot per class, the wave's counts as the bytes of
-// one word per class, then every thread finds its place from those eight words (v_sad_u8 sums a word's bytes) — fused with the
-// two barriers the queue append has anyway, one block iteration ahead like the stream prefetch. The streams of a window are
-// read once each, in a permuted order inside 4 KiB. Paths do not depend on which thread shades them: images stay bit-identical
-// (tests/test_gpu_pass_variants.py; TWK_SHADE_SORT=0 restores slot order).
-#define TWK_SHADE_CLASSES 8
-static_assert(TWK_SHADE_BLOCK <= 256, "the class sort keeps a slot offset in one byte");
-
-// order of the classes in a sorted window: the two that sample lights (Lambert, GGX reflection) side by side
-TWK_D unsigned int shadeClass(const ShadeTables& tables, int instanceIndex, bool inRange)
-{
-  if (!inRange) return 7u;
-  if (instanceIndex < 0) return 0u;                 // miss program
-  const DevInstance& inst = tables.instances[instanceIndex];
-  if (inst.light >= 0) return 1u;                   // light geometry
-  const int bsdf = tables.materials[inst.material].indexBSDF;
-  return (bsdf == 1) ? 2u : (bsdf == 2) ? 3u : (bsdf == 4) ? 4u : (bsdf == 3) ? 6u : 5u; // mirror, glass, rough glass, GGX, Lambert (default)
-}
-
-// Step 1 (before the block's first barrier): one returning LDS add per thread on its class counter = its rank in the class.
-// (The order inside a class is the order the adds arrive in — not the slot order, and not the same from run to run; no result
-// depends on which thread shades a path or on where its continuation lands in the queue. Round 5's first form ranked with eight
-// ballots per wave and v_sad_u8 sums: ~150 vector instructions per thread and window, which cost the kernel — bound by vector
-// issue — as much as the sorting won; this form issues ~30 and leaves the counting to the LDS unit.)
-TWK_D unsigned int sortCount(unsigned int key, unsigned int* classCount)
-{
-  return atomicAdd(classCount + key, 1u);
-}
-// Step 2 (between the barriers): the caller's place in the sorted window = threads of smaller classes + its rank.
-TWK_D unsigned int sortRank(unsigned int key, unsigned int rank, const unsigned int* classCount)
-{
-  const uint4 lo = *reinterpret_cast<const uint4*>(classCount), hi = *reinterpret_cast<const uint4*>(classCount + 4);
-  const unsigned int counts[TWK_SHADE_CLASSES] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  unsigned int place = rank;
-#pragma unroll
-  for (unsigned int c = 0; c + 1 < TWK_SHADE_CLASSES; ++c) place += (c < key) ? counts[c] : 0u;
-  return place;
-}
-// rotate: the sorted window starts at thread `rotate` and wraps — a multiple of 64 that differs from block to block and from
-// window to window. Without it wave 3 of EVERY block would shade the last classes (GGX, Lambert: the expensive ones) and wave 0 the
-// misses; a block's waves sit on the four SIMDs of its CU in order, so one SIMD of every CU would do most of the chip's shading.
-TWK_D void sortPlace(unsigned int key, unsigned int rank, const unsigned int* classCount, unsigned char* perm, int* permInstance, int instance, unsigned int rotate)
-{
-  unsigned int place = (sortRank(key, rank, classCount) + rotate) & (TWK_SHADE_BLOCK - 1u);
-#if TWK_SORT_GRANULE
-  // experiment: the sorted window is dealt to the four waves in granules of TWK_SORT_GRANULE lanes, so that every wave gets its
-  // share of every class (balanced waves at the block's barriers) in runs of that many lanes
-  { const unsigned int g = place / TWK_SORT_GRANULE, within = place % TWK_SORT_GRANULE, perWave = 64u / TWK_SORT_GRANULE;
-    place = (g % 4u) * 64u + (g / 4u) * TWK_SORT_GRANULE + within; (void) perWave; }
-#endif
-  perm[place] = (unsigned char) threadIdx.x;
-  permInstance[place] = instance;
-}
-// Experiment (tools/experiments/): the block's continuation rays are appended octant by octant of their
-// direction (1), the shadow rays too (2), so that the waves of the next traversal launch get rays that look the same way.
-#ifndef TWK_APPEND_OCTANTS
-#define TWK_APPEND_OCTANTS 0
-#endif
-TWK_D unsigned int directionOctant(const V3& d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
 
 // Primary rays. A pass used to start with generateKernel writing queue 0 — ray, pixel, throughput, seed and the black radiance
 // of every path, 76 bytes each, 157 MB per C2 iteration at the HBM write rate — for the first traversal and the first shade
@@ -209,10 +142,7 @@ TWK_D unsigned int directionOctant(const V3& d) { return (d.x < 0.0f ? 1u : 0u) 
 #ifndef TWK_SHADE_EXTRA_FMA
 #define TWK_SHADE_EXTRA_FMA 0
 #endif
-// SORT: the block shades its window in class order (above). A build per value: with the choice made at run time the two fetch
-// schedules coexist and the main variant spills 36 bytes at its 96 registers (16 with the sort alone, 8 without). The measurement
-// builds are instantiated with SORT = false and take LaunchParams::shadeSort instead.
-template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool MEASURE, bool SORT>
+template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool MEASURE>
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
@@ -226,8 +156,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   const int q = depth & 1, qn = q ^ 1;
   const bool packedIn = p.packedQueue != 0 && depth > 0, packedOut = p.packedQueue != 0; // queue 0 is computed (PRIMARY) or written by generateKernel
   ShadeInput in;
-  const bool sorted = MEASURE ? (p.shadeSort != 0) : SORT;
-  if (!sorted) loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
+  loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
 
   __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
   __shared__ unsigned int blockBase[2][2];
@@ -235,13 +164,6 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   unsigned int* const phaseLds = (MEASURE && p.stats != nullptr) ? phaseWords : nullptr;
   if (MEASURE) { if (threadIdx.x < 3 * TWK_SHADE_PHASES) phaseWords[threadIdx.x] = 0u; __syncthreads(); }
   const bool measurePhases = MEASURE && p.stats != nullptr; // time view alone: only the path time
-  __shared__ unsigned int classCount[2][TWK_SHADE_CLASSES];  // class sort: threads of the window per class (zero between uses)
-  __shared__ unsigned char permSlot[2][TWK_SHADE_BLOCK];     //   sorted position -> slot offset in the window
-  __shared__ int permInstance[2][TWK_SHADE_BLOCK];           //   ... and that slot's hit instance
-#if TWK_APPEND_OCTANTS
-  __shared__ unsigned int octantCount[2][2][TWK_SHADE_CLASSES]; // [buffer][shadow / continuation][octant]: appenders of the block (zero between uses)
-  if (threadIdx.x < 4 * TWK_SHADE_CLASSES) (&octantCount[0][0][0])[threadIdx.x] = 0u;
-#endif
 
   // Instance, material and light records in LDS (scenes whose tables fit): a hit reads ~16 float4 of them, each one divergent
   // lane address for the CU's vector memory path, which takes one per clock — the kernel's bound (rocprofv3: 0.9 lane
@@ -275,21 +197,6 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   // The kernel is bound by its chain of dependent fetches, not by arithmetic, so the chain is kept
   // short: the streams of the NEXT iteration's slot are requested between the two barriers of the append — they fly
   // while the block waits for its returning atomic — and nothing waits for the appended records to be written.
-  const unsigned int stride = gridDim.x * blockDim.x;
-  if (threadIdx.x < 2 * TWK_SHADE_CLASSES) (&classCount[0][0])[threadIdx.x] = 0u;
-  ldsBarrier(); // the counters are zero before anyone counts
-  if (sorted)
-  {
-    // the block's first window: sorted here, with two barriers of its own, through buffer 1 (the loop's first iteration uses 0)
-    const unsigned int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int instance = (slot < numRays) ? p.hitInstance[slot] : -1;
-    const unsigned int key = shadeClass(tables, instance, slot < numRays);
-    const unsigned int rank = sortCount(key, classCount[1]);
-    ldsBarrier();
-    sortPlace(key, rank, classCount[1], permSlot[1], permInstance[1], instance, (blockIdx.x & 3u) << 6);
-    ldsBarrier();
-    loadShadeInput<PRIMARY, true>(p, q, blockIdx.x * blockDim.x + permSlot[1][threadIdx.x], numRays, packedIn, in, permInstance[1][threadIdx.x]);
-  }
   unsigned int buffer = 0u;
 
   // block-uniform trip count: every thread reaches both barriers of every iteration
@@ -298,12 +205,6 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     ShadeOutput out;
     out.alive = false; out.wantShadow = false;
     const unsigned int pixel = in.pixel;
-    // class sort: the hit instance of this thread's slot of the NEXT window, requested a whole shadePath before it is looked at.
-    // (A block whose launch leaves it no further window — every block of the short queues of the deep bounces — sorts nothing.)
-    const unsigned int nextSlot = base + stride + threadIdx.x;
-    const bool sortNext = sorted && base + stride < numRays; // block-uniform
-    int nextInstance = -1;
-    if (sortNext && nextSlot < numRays) nextInstance = p.hitInstance[nextSlot];
     const unsigned int clockBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     const unsigned int iterationBegin = clockBegin;
     if (in.inRange && in.rd.w >= 0.0f) // else: beyond the queue, or an inactive launch index (tile column beyond the image)
@@ -340,29 +241,10 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
       waveCount[buffer][0][wave] = (unsigned int) __popcll(shadowMask);
       waveCount[buffer][1][wave] = (unsigned int) __popcll(nextMask);
     }
-#if TWK_APPEND_OCTANTS
-    const unsigned int nextOctant = directionOctant(out.nextDir);
-    const unsigned int nextOctantRank = out.alive ? sortCount(nextOctant, octantCount[buffer][1]) : 0u;
-#if TWK_APPEND_OCTANTS > 1
-    const unsigned int shadowOctant = directionOctant(out.shadowDir);
-    const unsigned int shadowOctantRank = out.wantShadow ? sortCount(shadowOctant, octantCount[buffer][0]) : 0u;
-#endif
-#endif
-    unsigned int nextKey = 0u, nextRank = 0u;
-    if (sortNext)
-    {
-      nextKey = shadeClass(tables, nextInstance, nextSlot < numRays);
-      nextRank = sortCount(nextKey, classCount[buffer]);
-    }
     ldsBarrier();
-    if (sortNext) sortPlace(nextKey, nextRank, classCount[buffer], permSlot[buffer], permInstance[buffer], nextInstance, ((blockIdx.x + 1u + (base - blockIdx.x * blockDim.x) / stride) & 3u) << 6);
     // (hipcc still waits for part of these right here — it copies one component of the hit record to another register
     // behind the loads; pinning the record at its first use makes that worse, every component then gets such a copy)
-    else if (!sorted) loadShadeInput<PRIMARY>(p, q, nextSlot, numRays, packedIn, in); // slot order: the streams fly while the block waits for its returning atomic
-    if (threadIdx.x < TWK_SHADE_CLASSES) classCount[buffer ^ 1u][threadIdx.x] = 0u; // used by the previous iteration, free until the next
-#if TWK_APPEND_OCTANTS
-    if (threadIdx.x < 2 * TWK_SHADE_CLASSES) (&octantCount[buffer ^ 1u][0][0])[threadIdx.x] = 0u; // the previous iteration's: every thread has read them
-#endif
+    loadShadeInput<PRIMARY>(p, q, base + gridDim.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
     if (threadIdx.x < 2)
     {
       unsigned int total = 0;
@@ -370,22 +252,12 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
       blockBase[buffer][threadIdx.x] = (total != 0u) ? atomicAdd((threadIdx.x == 0) ? shadowCount : nextCount, total) : 0u;
     }
     ldsBarrier();
-    // the streams of the next window's slot this thread shades: they fly while the appended records are written
-    if (sortNext) loadShadeInput<PRIMARY, true>(p, q, base + stride + permSlot[buffer][threadIdx.x], numRays, packedIn, in, permInstance[buffer][threadIdx.x]);
-    else if (sorted) in.inRange = false;
     unsigned int shadowOffset = blockBase[buffer][0], nextOffset = blockBase[buffer][1];
     for (unsigned int w = 0; w < wave; ++w) { shadowOffset += waveCount[buffer][0][w]; nextOffset += waveCount[buffer][1][w]; }
-    unsigned int shadowRank = (unsigned int) __popcll(shadowMask & laneBelow), appendRank = (unsigned int) __popcll(nextMask & laneBelow);
-#if TWK_APPEND_OCTANTS
-    nextOffset = blockBase[buffer][1]; appendRank = sortRank(nextOctant, nextOctantRank, octantCount[buffer][1]);
-#if TWK_APPEND_OCTANTS > 1
-    shadowOffset = blockBase[buffer][0]; shadowRank = sortRank(shadowOctant, shadowOctantRank, octantCount[buffer][0]);
-#endif
-#endif
 
     if (out.wantShadow)
     {
-      const unsigned int s = shadowOffset + shadowRank;
+      const unsigned int s = shadowOffset + (unsigned int) __popcll(shadowMask & laneBelow);
       p.shadowOrg[s]     = make_float4(out.nextPos.x, out.nextPos.y, out.nextPos.z, p.sceneEpsilon);
       p.shadowDir[s]     = make_float4(out.shadowDir.x, out.shadowDir.y, out.shadowDir.z, out.shadowTmax);
       p.shadowPixel[s]   = pixel;
@@ -393,7 +265,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     }
     if (out.alive)
     {
-      const unsigned int n = nextOffset + appendRank;
+      const unsigned int n = nextOffset + (unsigned int) __popcll(nextMask & laneBelow);
       if (packedOut)
       {
         // launch index + path flags and the LCG state ride in the record's two constant words: 12 bytes less written here, 12
@@ -586,15 +458,15 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);
 }
-template<bool PRIMARY, bool LDS_TABLES, bool MEASURE, bool SORT>
+template<bool PRIMARY, bool LDS_TABLES, bool MEASURE>
 static void launchShadeVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
   const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
-  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, MEASURE, SORT>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, MEASURE, SORT>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, MEASURE, SORT>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, MEASURE, SORT>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, MEASURE>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 // primary: depth 0 of a pass whose generateKernel was skipped ("primary rays" above)
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream)
@@ -603,18 +475,12 @@ void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks,
   const bool lds = TWK_SHADE_LDS_TABLES && tableBytes <= (size_t) TWK_SHADE_TABLE_BYTES;
   if (p.pathTime != nullptr || p.stats != nullptr) // time view, statistics: the measurement builds
   {
-    if (primary) { if (lds) launchShadeVariant<true, true, true, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, true, false>(p, depth, gridBlocks, stream); }
-    else         { if (lds) launchShadeVariant<false, true, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true, false>(p, depth, gridBlocks, stream); }
+    if (primary) { if (lds) launchShadeVariant<true, true, true>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, true>(p, depth, gridBlocks, stream); }
+    else         { if (lds) launchShadeVariant<false, true, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true>(p, depth, gridBlocks, stream); }
     return;
   }
-  if (p.shadeSort)
-  {
-    if (primary) { if (lds) launchShadeVariant<true, true, false, true>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false, true>(p, depth, gridBlocks, stream); }
-    else         { if (lds) launchShadeVariant<false, true, false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false, true>(p, depth, gridBlocks, stream); }
-    return;
-  }
-  if (primary) { if (lds) launchShadeVariant<true, true, false, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false, false>(p, depth, gridBlocks, stream); }
-  else         { if (lds) launchShadeVariant<false, true, false, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false, false>(p, depth, gridBlocks, stream); }
+  if (primary) { if (lds) launchShadeVariant<true, true, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false>(p, depth, gridBlocks, stream); }
+  else         { if (lds) launchShadeVariant<false, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false>(p, depth, gridBlocks, stream); }
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {
