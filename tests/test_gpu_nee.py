@@ -155,3 +155,39 @@ def test_switch_from_the_system_description(twk, orc):
     assert (_bits(gpu) != _bits(cpu)).any(axis=2).sum() == 0
     with pytest.raises(AssertionError):
         orc.Oracle(miss=app.info.miss).loadApplication(app)  # the NEE build of the oracle is not what this description asks for
+
+
+def test_shade_phase_tallies_of_the_measurement_build(twk):
+    """TwkLaunchStats.shadePhase* (ABI 9): per phase of the shading of a segment — wave executions, lanes, shader-clock cycles —
+    filled by the measurement builds while statistics are on. Consistency: every wave iteration runs the path phase and the
+    append; a phase never has more than 64 lanes per execution; the phases inside shadePath take no more time than the path;
+    the miss + hit lanes are the segments shaded; and with next-event estimation off the two NEE phases never run."""
+    L = twk._lib if hasattr(twk, "_lib") else None
+    PATH, MISS, HIT, NEE_SAMPLE, NEE_EVAL, APPEND, ITERATION = 0, 2, 3, 12, 13, 19, 20
+    app = load_app(twk, "system_rtigo3_cornell_box.txt", "scene_rtigo3_cornell_box.txt", (320, 180))
+    dev = twk.Device(ordinal=0, miss=app.info.miss)
+    app.initDevice(dev)
+    dev.render(0)
+    dev.synchronizeStream()
+    assert all(v == 0 for v in dev.statsGet(reset=True)["shadePhaseWaveSteps"]), "nothing is tallied with statistics off"
+    dev.statsEnable(True)
+    out = {}
+    for nee in (True, False):
+        dev.setNextEventEstimation(nee)
+        dev.statsGet(reset=True)
+        for it in range(4):
+            dev.render(it)
+        dev.synchronizeStream()
+        out[nee] = dev.statsGet(reset=True)
+    dev.close()
+    st = out[True]
+    ws, ln, cy = st["shadePhaseWaveSteps"], st["shadePhaseLanes"], st["shadePhaseCycles"]
+    assert ws[PATH] > 0 and ws[APPEND] == ws[ITERATION] >= ws[PATH]
+    for k in range(len(ws)):
+        assert ln[k] <= 64 * ws[k] and (ws[k] > 0) == (ln[k] > 0 or k == APPEND), k  # (an append with no appender still runs its barriers)
+    assert ln[MISS] + ln[HIT] == st["shadedHits"] + st["missed"] == ln[PATH]
+    assert sum(cy[k] for k in (1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 14, 15)) <= 1.02 * cy[PATH] <= 1.02 * cy[ITERATION]
+    assert 0.3 < ln[NEE_EVAL] / (64.0 * ws[NEE_EVAL]) <= 1.0 and ws[NEE_SAMPLE] >= ws[NEE_EVAL] > 0
+    off = out[False]
+    assert off["shadePhaseWaveSteps"][NEE_SAMPLE] == 0 and off["shadePhaseWaveSteps"][NEE_EVAL] == 0 and off["shadowRays"] == 0
+    assert off["shadePhaseWaveSteps"][PATH] > 0

@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     const unsigned int pixel = in.pixel;
     const unsigned int clockBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     const unsigned int iterationBegin = clockBegin;
+    const unsigned int slotLanes = MEASURE ? (unsigned int) __popcll(__ballot(in.inRange)) : 0u; // lanes of this wave with a queue slot in THIS window (`in` holds the next window's by the time the tallies are written)
     if (in.inRange && in.rd.w >= 0.0f) // else: beyond the queue, or an inactive launch index (tile column beyond the image)
     {
       if (measurePhases)
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
       const unsigned int now = (unsigned int) __builtin_readcyclecounter();
       atomicAdd(&phaseWords[SP_KERNEL_APPEND], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_KERNEL_APPEND], (unsigned int) __popcll(shadowMask | nextMask));
       atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_KERNEL_APPEND], now - appendBegin);
-      atomicAdd(&phaseWords[SP_KERNEL_ITERATION], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_KERNEL_ITERATION], (unsigned int) __popcll(__ballot(in.inRange)));
+      atomicAdd(&phaseWords[SP_KERNEL_ITERATION], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_KERNEL_ITERATION], slotLanes);
       atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_KERNEL_ITERATION], now - iterationBegin);
     }
   }
