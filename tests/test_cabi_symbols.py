@@ -96,3 +96,13 @@ def test_bench_carries_pmc_traffic_only_for_the_matching_launch_size():
     assert none is None and "no PMC record at this launch size" in why
     none, why = bench.pick_pmc_record(20, 20, (3840, 2160))
     assert none is None
+
+
+def test_switches_refuse_a_null_handle_without_touching_a_device():
+    """The run-time forms of the reference's compile-time switches (ABI 9 and before): a NULL handle is TWK_ERROR_INVALID_VALUE
+    with a message that names the call, before any HIP call — checkable without a GPU."""
+    from tweeker_raytracer_amd import _lib
+    for name in ("twk_set_next_event_estimation", "twk_set_debug_exceptions", "twk_set_time_view", "twk_enable_aov", "twk_set_shader_variant"):
+        rc = getattr(_lib.lib, name)(None, 1)
+        assert rc == _lib.TWK_ERROR_INVALID_VALUE, name
+        assert name in _lib.lib.twk_last_error().decode(), name
