@@ -191,7 +191,10 @@ enum
   TWK_SHADE_PHASE_AOV = 17,          /* denoiser AOV writes */
   TWK_SHADE_PHASE_KERNEL_LOAD = 18,  /* wait for the queue slot's streams */
   TWK_SHADE_PHASE_KERNEL_APPEND = 19,/* queue appends: ballots, barriers, the block's atomic, the stores (lanes = appending lanes) */
-  TWK_SHADE_PHASE_KERNEL_ITERATION = 20 /* one block iteration of the kernel, per wave (lanes = lanes with a queue slot) */
+  TWK_SHADE_PHASE_KERNEL_ITERATION = 20, /* one block iteration of the kernel, per wave (lanes = lanes with a queue slot) */
+  TWK_SHADE_PHASE_APPEND_BARRIER1 = 21,  /* of the append: from its start to behind the first barrier = the wait for the block's slowest wave */
+  TWK_SHADE_PHASE_APPEND_ATOMIC = 22,    /* the round trip of the block's returning atomic, per issuing lane */
+  TWK_SHADE_PHASE_APPEND_BARRIER2 = 23   /* from the first barrier to behind the second: stream requests, the atomic, the wait for it */
 };
 
 /* Accumulated device time per kernel class since twk_profile_reset (profiling mode only). */

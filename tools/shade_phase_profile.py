@@ -15,7 +15,8 @@ NAMES = ["path (whole shadePath)", "volume stack fetch", "miss program", "hit: r
          "implicit light hit", "sample: Lambert", "sample: mirror", "sample: glass", "sample: GGX brdf", "sample: GGX bsdf",
          "NEE: draws + light sampler", "NEE: BSDF eval + contribution", "radiance read-modify-write", "integrator tail (whole)",
          "volume stack push / pop", "AOV writes", "kernel: wait for the slot's streams", "kernel: append (ballots, barriers, atomic, stores)",
-         "kernel: block iteration (whole)"]
+         "kernel: block iteration (whole)", "append: to behind barrier 1 (slowest wave)", "append: the atomic's round trip (issuing lane)",
+         "append: barrier 1 to behind barrier 2"]
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 as_json = "--json" in sys.argv

@@ -73,7 +73,10 @@ enum ShadePhase
   SP_AOV,             // denoiser AOV writes
   SP_KERNEL_LOAD,     // shadeKernel: wait for the slot's streams (first use of the prefetched registers)
   SP_KERNEL_APPEND,   // shadeKernel: ballots, the block's two barriers and returning atomic, the queue writes
-  SP_KERNEL_ITERATION // shadeKernel: one block iteration, everything included
+  SP_KERNEL_ITERATION,// shadeKernel: one block iteration, everything included
+  SP_APPEND_BARRIER1, // ... of the append: from its start to behind the first barrier (the wait for the block's slowest wave)
+  SP_APPEND_ATOMIC,   // ... the round trip of the block's returning atomic (per issuing lane)
+  SP_APPEND_BARRIER2  // ... from the first barrier to behind the second (stream requests, the atomic, the wait for it)
 };
 template<bool MEASURE> struct PhaseScope
 {

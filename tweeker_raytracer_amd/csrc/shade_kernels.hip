@@ -142,6 +142,9 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 #ifndef TWK_SHADE_EXTRA_FMA
 #define TWK_SHADE_EXTRA_FMA 0
 #endif
+#ifndef TWK_PROBE_EXTRA_ATOMICS
+#define TWK_PROBE_EXTRA_ATOMICS 0
+#endif
 template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool MEASURE>
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
@@ -243,16 +246,38 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
       waveCount[buffer][1][wave] = (unsigned int) __popcll(nextMask);
     }
     ldsBarrier();
+    const unsigned int afterBarrier1 = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     // (hipcc still waits for part of these right here — it copies one component of the hit record to another register
     // behind the loads; pinning the record at its first use makes that worse, every component then gets such a copy)
     loadShadeInput<PRIMARY>(p, q, base + gridDim.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
+#if TWK_PROBE_EXTRA_ATOMICS // timing probe (profiles/r05_shade_diagnosis.md 7): that many more returning atomics per counter word and block iteration, adding a zero the compiler cannot see
+    if (threadIdx.x >= 2 && threadIdx.x < 2 + 2 * TWK_PROBE_EXTRA_ATOMICS)
+      blockBase[buffer ^ 1u][threadIdx.x & 1u] += atomicAdd((threadIdx.x & 1u) ? nextCount : shadowCount, (unsigned int) p.numPaths >> 31) & 0u;
+#endif
     if (threadIdx.x < 2)
     {
       unsigned int total = 0;
       for (unsigned int w = 0; w < TWK_SHADE_BLOCK / 64; ++w) total += waveCount[buffer][threadIdx.x][w];
+      const unsigned int atomicBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
       blockBase[buffer][threadIdx.x] = (total != 0u) ? atomicAdd((threadIdx.x == 0) ? shadowCount : nextCount, total) : 0u;
+      if (measurePhases && total != 0u)
+      {
+        // the round trip of the block's returning atomic, as the issuing lane sees it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicAdd(&phaseWords[SP_APPEND_ATOMIC], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_APPEND_ATOMIC], 1u);
+        atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_APPEND_ATOMIC], (unsigned int) __builtin_readcyclecounter() - atomicBegin);
+      }
     }
     ldsBarrier();
+    if (measurePhases && lane == 0)
+    {
+      // per wave: how long it stood at the first barrier (for the block's slowest wave) and at the second (for the atomic)
+      const unsigned int now = (unsigned int) __builtin_readcyclecounter();
+      atomicAdd(&phaseWords[SP_APPEND_BARRIER1], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_APPEND_BARRIER1], 64u);
+      atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_APPEND_BARRIER1], afterBarrier1 - appendBegin);
+      atomicAdd(&phaseWords[SP_APPEND_BARRIER2], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_APPEND_BARRIER2], 64u);
+      atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_APPEND_BARRIER2], now - afterBarrier1);
+    }
     unsigned int shadowOffset = blockBase[buffer][0], nextOffset = blockBase[buffer][1];
     for (unsigned int w = 0; w < wave; ++w) { shadowOffset += waveCount[buffer][0][w]; nextOffset += waveCount[buffer][1][w]; }
 
