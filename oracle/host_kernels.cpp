@@ -78,8 +78,9 @@ int hostk_render(const void* launchParams, size_t paramsBytes, unsigned int firs
   auto trace = [&](int depth)
   {
     // traceKernel's job for bounce `depth`: closest hits of queue depth & 1, then the shadow rays shade(depth - 1) emitted
-    const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
-    const unsigned int numShadow = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + 1] : 0u;
+    // (the host build appends in slot order to ONE segment of each queue — segment 0: device_types.h "queue segments")
+    const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST];
+    const unsigned int numShadow = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW] : 0u;
     const int q = depth & 1;
     for (unsigned int slot = 0; slot < numClosest; ++slot)
     {
@@ -114,10 +115,10 @@ int hostk_render(const void* launchParams, size_t paramsBytes, unsigned int firs
   {
     trace(depth);
     // shadeKernel: shadePath per queue slot, continuation and shadow rays appended in slot order
-    const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
+    const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST];
     const int q = depth & 1, qn = q ^ 1;
-    unsigned int& nextCount = p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + 0];
-    unsigned int& shadowCount = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 1];
+    unsigned int& nextCount = p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST];
+    unsigned int& shadowCount = p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW];
     for (unsigned int slot = 0; slot < numRays; ++slot)
     {
       const float4 ro = p.rayOrg[q][slot], rd = p.rayDir[q][slot];

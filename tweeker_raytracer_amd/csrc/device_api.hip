@@ -84,6 +84,8 @@ struct TileEntriesKey
   uint64_t buildSerial;
 };
 #define TWK_MAX_LANES 4
+#define TWK_LANE_QUEUE_PAD (TWK_QUEUE_SEGMENTS * 1024)                       // slots a lane's queue arrays may use beyond its path count (segment gaps: K x (255 + 512) at most)
+#define TWK_STREAM_PAD ((size_t) TWK_MAX_LANES * (TWK_LANE_QUEUE_PAD + 1024)) // ... of all lanes + the rounding of their shares
 #define TWK_STATS_WORDS 192 // device words of TwkLaunchStats: [0, 24) traversal + shade totals, [24, 96) the shade phases (shade_device.h PhaseScope); twice: the time view's scratch copy
 #define TWK_COUNTER_WORDS (TWK_COUNTERS_PER_DEPTH * (TWK_MAX_DEPTH + 2)) // one lane's counter block
 
@@ -276,6 +278,7 @@ static void refreshParams(TwkDevice dev)
   p.numPixels = dev->launchWidth * dev->state.resolution[1];
   p.batchCount = 1;
   p.numPaths = p.numPixels;
+  p.queueStride = TWK_QUEUE_STRIDE(p.numPaths);
   p.pathBase = 0;
   p.output = dev->d_outputExternal ? dev->d_outputExternal : dev->d_outputInternal;
   p.outputFrame = (dev->d_outputExternal && dev->outputFrame) ? 1 : 0;
@@ -323,8 +326,9 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
     const size_t n = (size_t) numPaths;
     // float4 streams: rayOrg[2], rayDir[2], rayThroughput[2], hitRecord, shadowOrg, shadowDir, shadowPending, radiance, volumeStack[4] = 15
     // 8-byte: raySeedFlags[2]; 4-byte: rayPixel[2], hitInstance, shadowPixel, overflowSlots[2]   → 280 bytes per path
-    const size_t bytes = n * (15 * sizeof(float4) + 2 * sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
-    if (dev->streamBudgetBytes != 0 && bytes > dev->streamBudgetBytes)
+    // (+ TWK_STREAM_PAD slots per stream: the segments of a queue leave gaps between them, device_types.h "queue segments")
+    const size_t bytes = (n + TWK_STREAM_PAD) * (15 * sizeof(float4) + 2 * sizeof(uint2) + 6 * sizeof(unsigned int)) + 4096;
+    if (dev->streamBudgetBytes != 0 && n * (15 * sizeof(float4) + 2 * sizeof(uint2) + 6 * sizeof(unsigned int)) > dev->streamBudgetBytes) // (the budget is for what grows with the pass, not for the fixed padding)
       return twkSetError(TWK_ERROR_OUT_OF_MEMORY, "path streams of " + std::to_string(bytes >> 20) + " MiB exceed TWK_STREAM_BUDGET_MB");
     HIP_TRY(hipMalloc(&dev->d_streamBlock, bytes));
     dev->allocatedPaths = numPaths;
@@ -377,7 +381,7 @@ static int ensureStreams(TwkDevice dev, int samples = 1)
   LaunchParams& p = dev->params;
   const size_t n = (size_t) dev->allocatedPaths;
   char* base = static_cast<char*>(dev->d_streamBlock);
-  auto take = [&](size_t elemBytes) { char* r = base; base += n * elemBytes; return r; };
+  auto take = [&](size_t elemBytes) { char* r = base; base += (n + TWK_STREAM_PAD) * elemBytes; return r; };
   p.rayOrg[0] = (float4*) take(16); p.rayOrg[1] = (float4*) take(16);
   p.rayDir[0] = (float4*) take(16); p.rayDir[1] = (float4*) take(16);
   p.hitRecord = (float4*) take(16);
@@ -553,12 +557,15 @@ static LaunchParams laneParams(TwkDevice dev, const LaunchParams& p, int lane, i
   const size_t share = ((total + lanes - 1) / lanes + 1023) & ~(size_t) 1023;
   const size_t base = std::min(total, share * lane), count = std::min(total - base, share);
   q.pathBase = (int) base; q.numPaths = (int) count;
+  q.queueStride = TWK_QUEUE_STRIDE(count);
+  // the queue arrays of a lane reach beyond its path count (the gaps between a queue's segments): their bases leave room for that
+  const size_t queueBase = (size_t) lane * (share + TWK_LANE_QUEUE_PAD);
   for (int k = 0; k < 2; ++k)
   {
-    q.rayOrg[k] += base; q.rayDir[k] += base; q.rayPixel[k] += base; q.rayThroughput[k] += base; q.raySeedFlags[k] += base;
+    q.rayOrg[k] += queueBase; q.rayDir[k] += queueBase; q.rayPixel[k] += queueBase; q.rayThroughput[k] += queueBase; q.raySeedFlags[k] += queueBase;
   }
   q.hitRecord += base; q.hitInstance += base;
-  q.shadowOrg += base; q.shadowDir += base; q.shadowPixel += base; q.shadowPending += base;
+  q.shadowOrg += queueBase; q.shadowDir += queueBase; q.shadowPixel += queueBase; q.shadowPending += queueBase;
   q.pathRadiance += base; q.overflowSlots += 2 * base;
   q.volumeStack += 4 * base; // [4][numPaths of the lane], indexed level * numPaths + path (shade_device.h)
   if (q.pathAlbedo) { q.pathAlbedo += base; q.pathNormal += base; }
@@ -577,6 +584,7 @@ static int renderPass(TwkDevice dev, unsigned int firstIteration, int count)
   p.batchCount = count;
   p.numPaths = p.numPixels * p.batchCount;
   p.pathBase = 0;
+  p.queueStride = TWK_QUEUE_STRIDE(p.numPaths);
 
   // launch index + path flags and the LCG state in the constant words of the queued rays (device_types.h LaunchParams::packedQueue)
   p.packedQueue = (dev->packedQueue && !p.hasCutout && (unsigned int) p.numPaths <= TWK_PACKED_PIXEL_MASK) ? 1 : 0;
@@ -1682,7 +1690,7 @@ try
     HIP_TRY(hipMemcpy(p.rayDir[1], dir.data(), numClosest * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.rayPixel[1], index.data(), numClosest * sizeof(unsigned int), hipMemcpyHostToDevice));
     const unsigned int c = (unsigned int) numClosest;
-    HIP_TRY(hipMemcpy(dev->d_counters + 1 * TWK_COUNTERS_PER_DEPTH + 0, &c, sizeof(c), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev->d_counters + 1 * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST, &c, sizeof(c), hipMemcpyHostToDevice)); // everything in segment 0
   }
   if (numShadow)
   {
@@ -1694,7 +1702,7 @@ try
     HIP_TRY(hipMemcpy(p.shadowPending, pending.data(), numShadow * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(p.pathRadiance, 0, numShadow * sizeof(float4)));
     const unsigned int c = (unsigned int) numShadow;
-    HIP_TRY(hipMemcpy(dev->d_counters + 0 * TWK_COUNTERS_PER_DEPTH + 1, &c, sizeof(c), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev->d_counters + 0 * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW, &c, sizeof(c), hipMemcpyHostToDevice));
   }
   launchTrace(p, 1, dev->statsEnabled, false, dev->numCUs * p.traceWaves, dev->stream);
   HIP_TRY(hipGetLastError());

@@ -226,13 +226,51 @@ struct LaunchParams
   // rayPixel / raySeedFlags streams are neither written nor read: 12 bytes less per path and bounce on both sides (TWK_PACKED_*).
   // Scenes without cutout opacity (its candidate loop keeps a per-ray tmin in the record), passes of fewer than 2^27 paths.
   int     packedQueue;
+  unsigned int queueStride; // slots between the starts of two queue segments (TWK_QUEUE_STRIDE of the pass's or the lane's path count)
   unsigned int* droppedPushes; // pinned host word (device-mapped): pushes the single-ray traversal could not store (trace_device.h TWK_PUSH); stays 0 on every scene twk_build accepts
 };
 
-// Counter block layout (unsigned int each), zeroed once per launch.
-// per depth d (0..maxDepth): [d*4+0] rays in queue d, [d*4+1] shadow rays emitted by shade d,
-// [d*4+2] chunk tickets of trace launch d (second half of a long queue), [d*4+3] rays of trace launch d that overflowed the LDS stack
-#define TWK_COUNTERS_PER_DEPTH 4
+// Queue segments (round 5). shadeKernel's time was the number of returning atomics on ONE counter word divided by the rate a word
+// sustains (87.8 per microsecond: profiles/r05_shade_diagnosis.md 7). So a queue is TWK_QUEUE_SEGMENTS regions of the same arrays,
+// each with a counter word of its own: the block that shades window w (256 slots) appends to segment w mod K, at
+// k * queueStride + the old value of that segment's counter. A consumer walks the segments one after the other: its VIRTUAL slot
+// v in [0, total) is record physicalSlot(v) — the hit records it writes / reads stay indexed by v. Queue 0 (primary rays, or
+// generateKernel's) and twk_debug_trace_queue's input are one segment: everything in segment 0.
+#ifndef TWK_QUEUE_SEGMENTS
+#define TWK_QUEUE_SEGMENTS 4
+#endif
+// Counter block layout (unsigned int each), zeroed once per launch. Per depth d (0..maxDepth), K = TWK_QUEUE_SEGMENTS:
+// [0, K) rays in segment k of queue d, [K, 2K) shadow rays emitted by shade d in segment k, [2K] chunk tickets of trace launch d
+// (second half of a long queue), [2K + 1] rays of trace launch d that overflowed the LDS stack.
+// The counters of a queue's segments lie TWK_COUNTER_SEGMENT_STRIDE words apart (their own cache lines / memory channels).
+#ifndef TWK_COUNTER_SEGMENT_STRIDE
+#define TWK_COUNTER_SEGMENT_STRIDE 64 // 256 bytes: measured 1 (one line for all) / 16 / 1024 words: shade 0.233 / 0.2235 / 0.2207 ms per step (exact), 0.230 / 0.173 / 0.172 (native-math build)
+#endif
+#define TWK_COUNTERS_PER_DEPTH (2 * TWK_QUEUE_SEGMENTS * TWK_COUNTER_SEGMENT_STRIDE + 2)
+#define TWK_COUNTER_CLOSEST  0
+#define TWK_COUNTER_SHADOW   (TWK_QUEUE_SEGMENTS * TWK_COUNTER_SEGMENT_STRIDE)
+#define TWK_COUNTER_TICKET   (2 * TWK_QUEUE_SEGMENTS * TWK_COUNTER_SEGMENT_STRIDE)
+#define TWK_COUNTER_OVERFLOW (2 * TWK_QUEUE_SEGMENTS * TWK_COUNTER_SEGMENT_STRIDE + 1)
+// Slots between the starts of two segments for a pass (or lane) of numPaths paths: segment k receives from at most
+// ceil(windows / K) windows of at most 256 rays each.
+#define TWK_QUEUE_STRIDE(numPaths) ((((unsigned int) (numPaths) / TWK_QUEUE_SEGMENTS + 255u) & ~255u) + 512u)
+
+struct QueueSegments { unsigned int first[TWK_QUEUE_SEGMENTS]; unsigned int total; }; // virtual slot of each segment's first ray; rays in all
+
+TWK_HD QueueSegments queueSegments(const unsigned int* counts)
+{
+  QueueSegments s; unsigned int sum = 0u;
+  for (int k = 0; k < TWK_QUEUE_SEGMENTS; ++k) { s.first[k] = sum; sum += counts[k * TWK_COUNTER_SEGMENT_STRIDE]; }
+  s.total = sum;
+  return s;
+}
+TWK_HD QueueSegments noSegments() { QueueSegments s; for (int k = 0; k < TWK_QUEUE_SEGMENTS; ++k) s.first[k] = 0u; s.total = 0u; return s; }
+TWK_HD unsigned int physicalSlot(const QueueSegments& s, unsigned int stride, unsigned int v)
+{
+  unsigned int k = 0u, f = 0u;
+  for (int j = 1; j < TWK_QUEUE_SEGMENTS; ++j) { const bool in = v >= s.first[j]; k += in ? 1u : 0u; f = in ? s.first[j] : f; }
+  return k * stride + (v - f);
+}
 #define TWK_MAX_DEPTH 64
 
 #ifndef TWK_TRACE_STACK_LDS

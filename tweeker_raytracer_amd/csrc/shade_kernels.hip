@@ -73,9 +73,12 @@ static_assert(TWK_FLAG_DIFFUSE == (1u << 2) && TWK_FLAG_ALBEDO == (1u << 28) && 
 
 // PRIMARY ("primary rays" below): queue 0 was never written; the slot's ray and path state are computed.
 // packed: the queue was written by shadeKernel in the packed form (device_types.h LaunchParams::packedQueue).
+// slot: the VIRTUAL slot (hit records are indexed by it); the queued ray and its path state sit at physicalSlot(slot)
+// (device_types.h "queue segments").
 template<bool PRIMARY>
-TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsigned int numRays, bool packed, ShadeInput& in)
+TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, const QueueSegments& segments, bool packed, ShadeInput& in)
 {
+  const unsigned int numRays = segments.total;
   in.inRange = slot < numRays;
   if (PRIMARY)
   {
@@ -95,11 +98,12 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
   }
   if (in.inRange)
   {
-    in.ro = p.rayOrg[q][slot];
-    in.rd = p.rayDir[q][slot];
+    const unsigned int record = physicalSlot(segments, p.queueStride, slot);
+    in.ro = p.rayOrg[q][record];
+    in.rd = p.rayDir[q][record];
     in.hit = p.hitRecord[slot];
     in.instanceIndex = p.hitInstance[slot];
-    in.throughputPdf = p.rayThroughput[q][slot];
+    in.throughputPdf = p.rayThroughput[q][record];
     if (packed)
     {
       const unsigned int word = __float_as_uint(in.ro.w);
@@ -109,8 +113,8 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, unsig
     }
     else
     {
-      in.pixel = p.rayPixel[q][slot];
-      in.seedFlags = p.raySeedFlags[q][slot];
+      in.pixel = p.rayPixel[q][record];
+      in.seedFlags = p.raySeedFlags[q][record];
     }
   }
 }
@@ -154,12 +158,13 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   // window. They leave HERE, before the table copy and its barrier — each used to hold a block slot for a global round trip: with 28 k
   // of 32 k blocks idle (1 M rays) that was half of the launch (round 5). The block's first window is requested at once, so that
   // its streams fly while the tables are copied.
-  const unsigned int numRays = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
+  const QueueSegments segments = queueSegments(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST]);
+  const unsigned int numRays = segments.total;
   if (blockIdx.x * blockDim.x >= numRays) return;
   const int q = depth & 1, qn = q ^ 1;
   const bool packedIn = p.packedQueue != 0 && depth > 0, packedOut = p.packedQueue != 0; // queue 0 is computed (PRIMARY) or written by generateKernel
   ShadeInput in;
-  loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
+  loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, segments, packedIn, in);
 
   __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
   __shared__ unsigned int blockBase[2][2];
@@ -190,8 +195,6 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     tables.lights    = reinterpret_cast<const DevLight*>(tableStorage + nI + nM);
     __syncthreads();
   }
-  unsigned int* nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + 0];
-  unsigned int* shadowCount = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 1];
   unsigned int statHit = 0, statMiss = 0;
 
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -208,6 +211,10 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     ShadeOutput out;
     out.alive = false; out.wantShadow = false;
     const unsigned int pixel = in.pixel;
+    // this window's segment of the two queues it appends to (device_types.h "queue segments"): a counter word of its own
+    const unsigned int segment = (base / TWK_SHADE_BLOCK) % TWK_QUEUE_SEGMENTS;
+    unsigned int* const nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST + segment * TWK_COUNTER_SEGMENT_STRIDE];
+    unsigned int* const shadowCount = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW + segment * TWK_COUNTER_SEGMENT_STRIDE];
     const unsigned int clockBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     const unsigned int iterationBegin = clockBegin;
     const unsigned int slotLanes = MEASURE ? (unsigned int) __popcll(__ballot(in.inRange)) : 0u; // lanes of this wave with a queue slot in THIS window (`in` holds the next window's by the time the tallies are written)
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
     const unsigned int afterBarrier1 = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     // (hipcc still waits for part of these right here — it copies one component of the hit record to another register
     // behind the loads; pinning the record at its first use makes that worse, every component then gets such a copy)
-    loadShadeInput<PRIMARY>(p, q, base + gridDim.x * blockDim.x + threadIdx.x, numRays, packedIn, in);
+    loadShadeInput<PRIMARY>(p, q, base + gridDim.x * blockDim.x + threadIdx.x, segments, packedIn, in);
 #if TWK_PROBE_EXTRA_ATOMICS // timing probe (profiles/r05_shade_diagnosis.md 7): that many more returning atomics per counter word and block iteration, adding a zero the compiler cannot see
     if (threadIdx.x >= 2 && threadIdx.x < 2 + 2 * TWK_PROBE_EXTRA_ATOMICS)
       blockBase[buffer ^ 1u][threadIdx.x & 1u] += atomicAdd((threadIdx.x & 1u) ? nextCount : shadowCount, (unsigned int) p.numPaths >> 31) & 0u;
@@ -278,7 +285,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
       atomicAdd(&phaseWords[SP_APPEND_BARRIER2], 1u); atomicAdd(&phaseWords[TWK_SHADE_PHASES + SP_APPEND_BARRIER2], 64u);
       atomicAdd(&phaseWords[2 * TWK_SHADE_PHASES + SP_APPEND_BARRIER2], now - afterBarrier1);
     }
-    unsigned int shadowOffset = blockBase[buffer][0], nextOffset = blockBase[buffer][1];
+    unsigned int shadowOffset = segment * p.queueStride + blockBase[buffer][0], nextOffset = segment * p.queueStride + blockBase[buffer][1];
     for (unsigned int w = 0; w < wave; ++w) { shadowOffset += waveCount[buffer][0][w]; nextOffset += waveCount[buffer][1][w]; }
 
     if (out.wantShadow)

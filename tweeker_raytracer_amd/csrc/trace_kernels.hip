@@ -39,11 +39,13 @@ __global__ void __launch_bounds__(TWK_TRACE_BLOCK)
 traceOverflowKernel(LaunchParams p, int depth)
 {
   __shared__ int stackStorage[TWK_TRACE_STACK_LDS * TWK_TRACE_BLOCK];
-  const unsigned int count = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3];
+  const unsigned int count = p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_OVERFLOW];
   if (count == 0u) return;
   int* ldsStack = stackStorage + threadIdx.x;
   int* spill = p.traceStackSpill + (size_t) (blockIdx.x * blockDim.x + threadIdx.x) * TWK_TRACE_STACK_SPILL;
-  const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
+  const QueueSegments closestSegments = queueSegments(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST]);
+  const QueueSegments shadowSegments  = (depth > 0) ? queueSegments(&p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW]) : noSegments();
+  const unsigned int numClosest = closestSegments.total;
   const int q = depth & 1;
   const bool packed = !CUTOUT && !PRIMARY && p.packedQueue != 0 && depth > 0; // as in traceKernel
   unsigned int nodeCount = 0, triCount = 0, instCount = 0;
@@ -51,6 +53,8 @@ traceOverflowKernel(LaunchParams p, int depth)
   {
     const unsigned int slot = p.overflowSlots[k];
     const bool isShadow = !(slot < numClosest);
+    // the ray's record in its queue (device_types.h "queue segments"); the hit record stays indexed by the launch's slot
+    const unsigned int record = isShadow ? physicalSlot(shadowSegments, p.queueStride, slot - numClosest) : (PRIMARY ? slot : physicalSlot(closestSegments, p.queueStride, slot));
     float4 o, d;
     if (PRIMARY)
     {
@@ -60,8 +64,8 @@ traceOverflowKernel(LaunchParams p, int depth)
     }
     else
     {
-      o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
-      d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+      o = isShadow ? p.shadowOrg[record] : p.rayOrg[q][record];
+      d = isShadow ? p.shadowDir[record] : p.rayDir[q][record];
     }
     const unsigned int packedPixel = __float_as_uint(o.w) & TWK_PACKED_PIXEL_MASK;
     if (packed && !isShadow) { o.w = p.sceneEpsilon; d.w = RT_DEFAULT_MAX; }
@@ -71,25 +75,25 @@ traceOverflowKernel(LaunchParams p, int depth)
     for (;;)
     {
       traverse<COUNT>(p, v3(o), v3(d), tmin, d.w, isShadow && !CUTOUT, ldsStack, spill, res, nodeCount, triCount, instCount);
-      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY))) break;
+      if (!(CUTOUT && res.instance >= 0 && cutoutIgnoresCandidate(p, res, isShadow, q, record, PRIMARY))) break;
       tmin = res.t;
     }
     if (COUNT && p.pathTime != nullptr)
-      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[slot - numClosest] : (PRIMARY ? slot : (packed ? packedPixel : p.rayPixel[q][slot]))], float((unsigned int) __builtin_readcyclecounter() - rayClock));
+      atomicAdd(&p.pathTime[isShadow ? p.shadowPixel[record] : (PRIMARY ? slot : (packed ? packedPixel : p.rayPixel[q][record]))], float((unsigned int) __builtin_readcyclecounter() - rayClock));
     if (!isShadow)
     {
       p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
       p.hitInstance[slot] = res.instance;
       if (p.firstHit != nullptr && depth == 0)
       {
-        const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
+        const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][record];
         p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
         p.firstHitInstance[pixel] = res.instance;
       }
     }
     else if (res.instance < 0)
     {
-      const unsigned int sIdx = slot - numClosest;
+      const unsigned int sIdx = record;
       const unsigned int pixel = p.shadowPixel[sIdx];
       const float4 c = p.shadowPending[sIdx];
       float4 r = p.pathRadiance[pixel];

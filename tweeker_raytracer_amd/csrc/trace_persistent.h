@@ -27,7 +27,8 @@ namespace twk {
 // traceOverflowKernel continues behind the same candidate.
 // primary: a ray of the fused first launch (PRIMARY builds): queue 0 holds its seed (stored at the refill) but no ray record —
 // the new tmin stays in the caller's register and is handed to traceOverflowKernel through the hit record (see there).
-TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res, bool isShadow, int q, unsigned int slot, unsigned int numClosest, bool primary = false)
+// record: the physical index of the ray's record in its queue (device_types.h "queue segments").
+TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res, bool isShadow, int q, unsigned int record, bool primary = false)
 {
   const DevInstance& inst = p.instances[res.instance];
   const DevMaterial& material = p.materials[inst.material];
@@ -41,20 +42,20 @@ TWK_D bool cutoutIgnoresCandidate(const LaunchParams& p, const TraceResult& res,
   float draw;
   if (isShadow)
   {
-    float4 pend = p.shadowPending[slot - numClosest];
+    float4 pend = p.shadowPending[record];
     unsigned int seed = __float_as_uint(pend.w);
     draw = rng(seed);
     pend.w = __uint_as_float(seed);
-    p.shadowPending[slot - numClosest] = pend;
+    p.shadowPending[record] = pend;
   }
   else
   {
-    uint2 sf = p.raySeedFlags[q][slot];
+    uint2 sf = p.raySeedFlags[q][record];
     draw = rng(sf.x);
-    p.raySeedFlags[q][slot] = sf;
+    p.raySeedFlags[q][record] = sf;
   }
   if (!(opacity <= draw)) return false;
-  if (isShadow) p.shadowOrg[slot - numClosest].w = res.t; else if (!primary) p.rayOrg[q][slot].w = res.t;
+  if (isShadow) p.shadowOrg[record].w = res.t; else if (!primary) p.rayOrg[q][record].w = res.t;
   return true;
 }
 
@@ -113,9 +114,13 @@ traceKernel(LaunchParams p, int depth)
   }
   __syncthreads();
 
-  const unsigned int numClosest = p.counters[depth * TWK_COUNTERS_PER_DEPTH + 0];
-  const unsigned int numShadow  = (depth > 0) ? p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + 1] : 0u;
+  // the two queues of this launch, each in segments (device_types.h "queue segments"): a slot of the launch is a VIRTUAL slot
+  const QueueSegments closestSegments = queueSegments(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST]);
+  const QueueSegments shadowSegments  = (depth > 0) ? queueSegments(&p.counters[(depth - 1) * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW]) : noSegments();
+  const unsigned int numClosest = closestSegments.total, numShadow = shadowSegments.total;
   const unsigned int total = numClosest + numShadow;
+  // physical record of a slot in its queue; PRIMARY: queue 0 is the identity
+#define TWK_RECORD(slot_) (((slot_) < numClosest) ? (PRIMARY ? (slot_) : physicalSlot(closestSegments, p.queueStride, (slot_))) : physicalSlot(shadowSegments, p.queueStride, (slot_) - numClosest))
 
   const int q = depth & 1;
   const bool packed = !CUTOUT && !PRIMARY && p.packedQueue != 0 && depth > 0; // device_types.h LaunchParams::packedQueue: the closest-hit rays' .w words are not tmin / tmax
@@ -154,7 +159,7 @@ traceKernel(LaunchParams p, int depth)
   if (nextChunk >= total) return; // nothing for this wave
   unsigned int poolBase = 0u, poolCount = 0u;
 #if TWK_TRACE_TAIL_DEN
-  unsigned int* ticket = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + 2];
+  unsigned int* ticket = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_TICKET];
   const unsigned int staticEnd = longQueue ? ((total - total / TWK_TRACE_TAIL_DEN) / (numWaves * ticketSize)) * (numWaves * ticketSize) : total;
 #else
   const unsigned int staticEnd = total;
@@ -205,13 +210,13 @@ traceKernel(LaunchParams p, int depth)
         // LDS stack overflow: hand the ray to traceOverflowKernel (spilling single-ray traversal), which runs
         // right behind this launch; nothing is written for it here.
         state = (state & ~ST_RETRACE) | ST_OVERFLOWED;
-        const unsigned int k = atomicAdd(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + 3], 1u);
+        const unsigned int k = atomicAdd(&p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_OVERFLOW], 1u);
         p.overflowSlots[k] = slot;
         if (PRIMARY && CUTOUT) p.hitRecord[slot] = make_float4(tmin, 0.0f, 0.0f, 0.0f); // where the re-trace continues: behind the candidates ignored so far
       }
       if (COUNT) maxSteps = max(maxSteps, guard);
       const bool ignoredCandidate = CUTOUT && !(state & ST_OVERFLOWED) && res.instance >= 0 &&
-                                    cutoutIgnoresCandidate(p, res, isShadow, q, slot, numClosest, PRIMARY);
+                                    cutoutIgnoresCandidate(p, res, isShadow, q, TWK_RECORD(slot), PRIMARY);
       if (ignoredCandidate)
       {
         // continue strictly behind the ignored candidate: the traversal starts again with tmin = its distance. The ray comes from
@@ -227,8 +232,9 @@ traceKernel(LaunchParams p, int depth)
         }
         else
         {
-          o = isShadow ? p.shadowOrg[slot - numClosest] : p.rayOrg[q][slot];
-          d = isShadow ? p.shadowDir[slot - numClosest] : p.rayDir[q][slot];
+          const unsigned int record = TWK_RECORD(slot);
+          o = isShadow ? p.shadowOrg[record] : p.rayOrg[q][record];
+          d = isShadow ? p.shadowDir[record] : p.rayDir[q][record];
         }
         org = v3(o); dir = v3(d);
         res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
@@ -245,10 +251,10 @@ traceKernel(LaunchParams p, int depth)
         p.hitRecord[slot]   = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.triangleSlot));
         p.hitInstance[slot] = res.instance;
         if (COUNT) ++closestCount;
-        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : (packed ? (__float_as_uint(p.rayOrg[q][slot].w) & TWK_PACKED_PIXEL_MASK) : p.rayPixel[q][slot])], float(rayCycles)); // time view: the lane's cycles from taking the ray to its completion
+        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[PRIMARY ? slot : (packed ? (__float_as_uint(p.rayOrg[q][TWK_RECORD(slot)].w) & TWK_PACKED_PIXEL_MASK) : p.rayPixel[q][TWK_RECORD(slot)])], float(rayCycles)); // time view: the lane's cycles from taking the ray to its completion
         if (p.firstHit != nullptr && depth == 0)
         {
-          const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][slot];
+          const unsigned int pixel = PRIMARY ? slot : p.rayPixel[q][TWK_RECORD(slot)];
           p.firstHit[pixel] = make_float4(res.t, res.beta, res.gamma, __int_as_float(res.primitive));
           p.firstHitInstance[pixel] = res.instance;
         }
@@ -256,11 +262,11 @@ traceKernel(LaunchParams p, int depth)
       else
       {
         if (COUNT) ++shadowCount;
-        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[p.shadowPixel[slot - numClosest]], float(rayCycles));
+        if (COUNT && p.pathTime != nullptr) atomicAdd(&p.pathTime[p.shadowPixel[TWK_RECORD(slot)]], float(rayCycles));
         if (res.instance < 0)
         {
           // visible: add the pending next-event contribution (closesthit.cu:288-299, raygeneration.cu:100)
-          const unsigned int s = slot - numClosest;
+          const unsigned int s = TWK_RECORD(slot);
           const unsigned int pixel = p.shadowPixel[s];
           const float4 c = p.shadowPending[s];
           float4 r = p.pathRadiance[pixel];
@@ -318,10 +324,15 @@ traceKernel(LaunchParams p, int depth)
             }
             else if (slot < numClosest)
             {
-              o = p.rayOrg[q][slot]; d = p.rayDir[q][slot]; state = ST_HAS_RAY;
+              const unsigned int record = physicalSlot(closestSegments, p.queueStride, slot);
+              o = p.rayOrg[q][record]; d = p.rayDir[q][record]; state = ST_HAS_RAY;
               if (packed) { o.w = p.sceneEpsilon; d.w = RT_DEFAULT_MAX; }
             }
-            else                   { o = p.shadowOrg[slot - numClosest]; d = p.shadowDir[slot - numClosest]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT); }
+            else
+            {
+              const unsigned int record = physicalSlot(shadowSegments, p.queueStride, slot - numClosest);
+              o = p.shadowOrg[record]; d = p.shadowDir[record]; state = ST_HAS_RAY | ST_SHADOW | (CUTOUT ? 0u : ST_ANY_HIT);
+            }
             org = v3(o); dir = v3(d); tmin = o.w;
             res.t = d.w; res.beta = 0.0f; res.gamma = 0.0f; res.instance = -1; res.primitive = -1; res.triangleSlot = -1;
             setupRay(ray, org, dir);
@@ -576,6 +587,7 @@ traceKernel(LaunchParams p, int depth)
   }
 #undef TWK_WAVE_STEP
 #undef TWK_PHASE_END
+#undef TWK_RECORD
 }
 
 } // namespace twk
