@@ -7,7 +7,7 @@ for spec in "$@"; do
   lib=""; [[ "$name" != "base" ]] && lib="TWK_LIB=build/lib_$name.so"
   for steps in "20 5" "64 4"; do
     set -- $steps
-    out=gpurun_out/ab2_${spec//[:=,]/_}_s$1.json
+    out=gpurun_out/ab2_${spec//[:=,\/]/_}_s$1.json
     env $lib ${envs//,/ } timeout -k 10 300 python3 bench.py --steps $1 --warmup $2 --no-cpu-baseline > $out 2>/dev/null
     python3 - "$spec" "$out" $1 <<'PY'
 import json, sys

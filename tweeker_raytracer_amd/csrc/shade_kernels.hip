@@ -123,6 +123,65 @@ TWK_D void loadShadeInput(const LaunchParams& p, int q, unsigned int slot, const
 // (s_waitcnt vmcnt(0)), which is exactly what the two barriers of the append must not do: see shadeKernel.
 TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---------------------------------------------------------------------------------------------
+// Class-coherent execution (round 5). The shading of a segment branches on what was hit — nothing, a light, one of five BSDFs —
+// and a wave pays for every branch any of its lanes takes: on C2 the GGX wall's tangent frame, sample and eval ran in 53 % of the
+// wave iterations with 10 % of the lanes (profiles/r05a_shade_phases_c2_b20.txt). So the block sorts its window of TWK_SHADE_BLOCK
+// queue slots by class before it shades them — a counting sort through LDS: one returning LDS add per thread on its class
+// counter, its place = the threads of smaller classes + its rank — and the threads EXCHANGE what they loaded: every thread reads
+// its slot's streams in slot order exactly as without the sort (coalesced, requested a block iteration ahead), stores them at its
+// place of the exchange buffer, and takes over the record of the slot it shades. Paths do not depend on which thread shades them:
+// images stay bit-identical (tests/test_gpu_pass_variants.py; TWK_SHADE_SORT=0 restores slot order).
+// History: a sort that LOADED in sorted order (hit instance first, then the streams of slot window + perm[t]) was built in rounds
+// 2, 3 and 5: -38 % vector instructions, lanes per instruction 0.37 -> 0.65, and never faster — until round 5 the kernel stood on
+// the returning atomic of one counter word (profiles/r05_shade_diagnosis.md 7), and after that the dependent second fetch cost a
+// memory round trip per window, which most blocks cannot hide (the grid gives a block one or two windows).
+#define TWK_SHADE_CLASSES 8
+#ifndef TWK_SHADE_SORT_TABLE_BYTES
+#define TWK_SHADE_SORT_TABLE_BYTES 8192 // table budget of the builds that carry the exchange buffer (20 KiB): five blocks per CU = 145 of 160 KiB
+#endif
+static_assert(TWK_SHADE_BLOCK == 256, "the class sort's places are 8 bits");
+
+// order of the classes in a sorted window: the two that sample lights (Lambert, GGX reflection) side by side
+TWK_D unsigned int shadeClass(const ShadeTables& tables, int instanceIndex, bool active)
+{
+  if (!active) return 7u;                           // beyond the queue, or an inactive launch index
+  if (instanceIndex < 0) return 0u;                 // miss program
+  const DevInstance& inst = tables.instances[instanceIndex];
+  if (inst.light >= 0) return 1u;                   // light geometry
+  const int bsdf = tables.materials[inst.material].indexBSDF;
+  return (bsdf == 1) ? 2u : (bsdf == 2) ? 3u : (bsdf == 4) ? 4u : (bsdf == 3) ? 6u : 5u; // mirror, glass, rough glass, GGX; Lambert (default)
+}
+// What a thread hands over: the streams of one queue slot as loaded (ShadeInput), 80 bytes, as four 16-byte rows + four words.
+struct ShadeExchange
+{
+  float4 ro[TWK_SHADE_BLOCK], rd[TWK_SHADE_BLOCK], hit[TWK_SHADE_BLOCK], throughputPdf[TWK_SHADE_BLOCK];
+  uint4  words[TWK_SHADE_BLOCK]; // seed, flags, pixel (all ones: no slot), instance
+};
+// rotate: the sorted window starts at thread `rotate` and wraps — a multiple of 64 that differs from block to block and from
+// window to window. Without it wave 3 of EVERY block would shade the last classes (Lambert, GGX: the expensive ones) and wave 0 the
+// misses; a block's waves sit on the four SIMDs of its CU in order, so one SIMD of every CU would do most of the chip's shading.
+TWK_D void sortExchange(const ShadeTables& tables, unsigned int* classCount, ShadeExchange& x, unsigned int rotate, ShadeInput& in)
+{
+  const bool active = in.inRange && in.rd.w >= 0.0f;
+  const unsigned int key = shadeClass(tables, in.instanceIndex, active);
+  const unsigned int rank = atomicAdd(classCount + key, 1u); // the order inside a class is the order the adds arrive in: no result depends on it
+  ldsBarrier();
+  const uint4 lo = *reinterpret_cast<const uint4*>(classCount), hi = *reinterpret_cast<const uint4*>(classCount + 4);
+  const unsigned int counts[TWK_SHADE_CLASSES] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  unsigned int place = rank + rotate;
+#pragma unroll
+  for (unsigned int c = 0; c + 1 < TWK_SHADE_CLASSES; ++c) place += (c < key) ? counts[c] : 0u;
+  place &= TWK_SHADE_BLOCK - 1u;
+  x.ro[place] = in.ro; x.rd[place] = in.rd; x.hit[place] = in.hit; x.throughputPdf[place] = in.throughputPdf;
+  x.words[place] = make_uint4(in.seedFlags.x, in.seedFlags.y, in.inRange ? in.pixel : 0xFFFFFFFFu, (unsigned int) in.instanceIndex);
+  ldsBarrier();
+  if (threadIdx.x < TWK_SHADE_CLASSES) classCount[threadIdx.x] = 0u; // every thread has read the counts; the next window counts behind two more barriers
+  in.ro = x.ro[threadIdx.x]; in.rd = x.rd[threadIdx.x]; in.hit = x.hit[threadIdx.x]; in.throughputPdf = x.throughputPdf[threadIdx.x];
+  const uint4 w = x.words[threadIdx.x];
+  in.seedFlags = make_uint2(w.x, w.y); in.pixel = w.z; in.inRange = (w.z != 0xFFFFFFFFu); in.instanceIndex = (int) w.w;
+}
+
 // Primary rays. A pass used to start with generateKernel writing queue 0 — ray, pixel, throughput, seed and the black radiance
 // of every path, 76 bytes each, 157 MB per C2 iteration at the HBM write rate — for the first traversal and the first shade
 // launch to read back. Both now COMPUTE the primary ray of their slot (shade_device.h primaryRay: 60 integer operations for
@@ -149,7 +208,9 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 #ifndef TWK_PROBE_EXTRA_ATOMICS
 #define TWK_PROBE_EXTRA_ATOMICS 0
 #endif
-template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool MEASURE>
+// SORT: the block shades its window in class order (above; LDS_TABLES builds only). The measurement builds carry the exchange
+// buffer too and take LaunchParams::shadeSort at run time.
+template<bool ENV, bool TEX, bool PRIMARY, bool LDS_TABLES, bool MEASURE, bool SORT>
 __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (PRIMARY ? TWK_SHADE_WAVES_PRIMARY : TWK_SHADE_WAVES)) shadeKernel(LaunchParams p, int depth)
 {
   // Double-buffered by block iteration: iteration i + 2 rewrites what i used only after every thread has passed a barrier
@@ -172,6 +233,11 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   unsigned int* const phaseLds = (MEASURE && p.stats != nullptr) ? phaseWords : nullptr;
   if (MEASURE) { if (threadIdx.x < 3 * TWK_SHADE_PHASES) phaseWords[threadIdx.x] = 0u; __syncthreads(); }
   const bool measurePhases = MEASURE && p.stats != nullptr; // time view alone: only the path time
+  constexpr bool EXCHANGE = LDS_TABLES && (SORT || MEASURE);
+  const bool sorted = LDS_TABLES && (MEASURE ? (p.shadeSort != 0) : SORT);
+  __shared__ __attribute__((aligned(16))) unsigned int classCount[TWK_SHADE_CLASSES]; // class sort: threads of the window per class (zero between uses)
+  __shared__ float4 exchangeStorage[EXCHANGE ? sizeof(ShadeExchange) / 16 : 1];
+  if (EXCHANGE && threadIdx.x < TWK_SHADE_CLASSES) classCount[threadIdx.x] = 0u; // the table copy's barrier is behind this
 
   // Instance, material and light records in LDS (scenes whose tables fit): a hit reads ~16 float4 of them, each one divergent
   // lane address for the CU's vector memory path, which takes one per clock — the kernel's bound (rocprofv3: 0.9 lane
@@ -179,7 +245,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   // (profiles/r02a_gather_probe2.txt).
   ShadeTables tables;
   tables.instances = p.instances; tables.materials = p.materials; tables.lights = p.lights;
-  __shared__ float4 tableStorage[LDS_TABLES ? TWK_SHADE_TABLE_BYTES / 16 : 1];
+  __shared__ float4 tableStorage[LDS_TABLES ? (EXCHANGE ? TWK_SHADE_SORT_TABLE_BYTES : TWK_SHADE_TABLE_BYTES) / 16 : 1];
   if (LDS_TABLES)
   {
     // launchShade has checked that the three tables fit. The pointers are LDS pointers at compile time: the reads of the
@@ -210,14 +276,15 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   {
     ShadeOutput out;
     out.alive = false; out.wantShadow = false;
-    const unsigned int pixel = in.pixel;
     // this window's segment of the two queues it appends to (device_types.h "queue segments"): a counter word of its own
     const unsigned int segment = (base / TWK_SHADE_BLOCK) % TWK_QUEUE_SEGMENTS;
     unsigned int* const nextCount   = &p.counters[(depth + 1) * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_CLOSEST + segment * TWK_COUNTER_SEGMENT_STRIDE];
     unsigned int* const shadowCount = &p.counters[depth * TWK_COUNTERS_PER_DEPTH + TWK_COUNTER_SHADOW + segment * TWK_COUNTER_SEGMENT_STRIDE];
     const unsigned int clockBegin = MEASURE ? (unsigned int) __builtin_readcyclecounter() : 0u;
     const unsigned int iterationBegin = clockBegin;
+    if (EXCHANGE && sorted) sortExchange(tables, classCount, *reinterpret_cast<ShadeExchange*>(exchangeStorage), ((blockIdx.x + base / (gridDim.x * blockDim.x)) & 3u) << 6, in);
     const unsigned int slotLanes = MEASURE ? (unsigned int) __popcll(__ballot(in.inRange)) : 0u; // lanes of this wave with a queue slot in THIS window (`in` holds the next window's by the time the tallies are written)
+    const unsigned int pixel = in.pixel;
     if (in.inRange && in.rd.w >= 0.0f) // else: beyond the queue, or an inactive launch index (tile column beyond the image)
     {
       if (measurePhases)
@@ -491,29 +558,35 @@ void launchGenerate(const LaunchParams& p, hipStream_t stream)
 {
   hipLaunchKernelGGL(generateKernel, dim3((p.numPaths + 255) / 256), dim3(256), 0, stream, p);
 }
-template<bool PRIMARY, bool LDS_TABLES, bool MEASURE>
+template<bool PRIMARY, bool LDS_TABLES, bool MEASURE, bool SORT>
 static void launchShadeVariant(const LaunchParams& p, int depth, int gridBlocks, hipStream_t stream)
 {
   // the variant without what the scene does not have (shade_device.h shadePath): spherical environment, albedo textures
   const bool env = (p.miss == 2), tex = (p.hasAlbedoTexture != 0);
-  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, MEASURE>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
-  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, MEASURE>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  if (env && tex)  hipLaunchKernelGGL((shadeKernel<true, true, PRIMARY, LDS_TABLES, MEASURE, SORT>),  dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (env)    hipLaunchKernelGGL((shadeKernel<true, false, PRIMARY, LDS_TABLES, MEASURE, SORT>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else if (tex)    hipLaunchKernelGGL((shadeKernel<false, true, PRIMARY, LDS_TABLES, MEASURE, SORT>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
+  else             hipLaunchKernelGGL((shadeKernel<false, false, PRIMARY, LDS_TABLES, MEASURE, SORT>), dim3(gridBlocks), dim3(TWK_SHADE_BLOCK), 0, stream, p, depth);
 }
 // primary: depth 0 of a pass whose generateKernel was skipped ("primary rays" above)
 void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks, hipStream_t stream)
 {
   const size_t tableBytes = (size_t) p.numInstances * sizeof(DevInstance) + (size_t) p.numMaterials * sizeof(DevMaterial) + (size_t) p.numLights * sizeof(DevLight);
   const bool lds = TWK_SHADE_LDS_TABLES && tableBytes <= (size_t) TWK_SHADE_TABLE_BYTES;
+  const bool ldsSort = TWK_SHADE_LDS_TABLES && tableBytes <= (size_t) TWK_SHADE_SORT_TABLE_BYTES; // the builds with the exchange buffer hold smaller tables
   if (p.pathTime != nullptr || p.stats != nullptr) // time view, statistics: the measurement builds
   {
-    if (primary) { if (lds) launchShadeVariant<true, true, true>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, true>(p, depth, gridBlocks, stream); }
-    else         { if (lds) launchShadeVariant<false, true, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true>(p, depth, gridBlocks, stream); }
+    if (primary) { if (ldsSort) launchShadeVariant<true, true, true, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, true, false>(p, depth, gridBlocks, stream); }
+    else         { if (ldsSort) launchShadeVariant<false, true, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true, false>(p, depth, gridBlocks, stream); }
     return;
   }
-  if (primary) { if (lds) launchShadeVariant<true, true, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false>(p, depth, gridBlocks, stream); }
-  else         { if (lds) launchShadeVariant<false, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false>(p, depth, gridBlocks, stream); }
+  if (p.shadeSort && ldsSort)
+  {
+    if (primary) launchShadeVariant<true, true, false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, true, false, true>(p, depth, gridBlocks, stream);
+    return;
+  }
+  if (primary) { if (lds) launchShadeVariant<true, true, false, false>(p, depth, gridBlocks, stream);  else launchShadeVariant<true, false, false, false>(p, depth, gridBlocks, stream); }
+  else         { if (lds) launchShadeVariant<false, true, false, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, false, false>(p, depth, gridBlocks, stream); }
 }
 void launchAccumulate(const LaunchParams& p, hipStream_t stream)
 {
