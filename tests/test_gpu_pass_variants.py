@@ -39,7 +39,7 @@ def _render(twk, app, iterations, index=0, count=1, batch=None):
     return out, info
 
 
-KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0"), ("TWK_TILE_ENTRIES", "0"), ("TWK_WIDE_ROOT", "0"), ("TWK_SHADE_SORT", "0")]
+KNOBS = [("TWK_DIRECT_SMALL_LEAVES", "0"), ("TWK_COSTED_CUTS", "0"), ("TWK_TRACE_WAVES_RUNTIME", "6"), ("TWK_FUSED_PRIMARY", "0"), ("TWK_TILE_ENTRIES", "0"), ("TWK_WIDE_ROOT", "0"), ("TWK_SHADE_SORT", "0"), ("TWK_SHADE_SORT", "2")]
 
 
 @pytest.mark.parametrize("system,scene,res", [

@@ -135,7 +135,7 @@ struct TwkDevice_t
   unsigned int* h_dropped = nullptr; unsigned int* d_dropped = nullptr; // pinned + device-mapped: LaunchParams::droppedPushes
   int* d_spill = nullptr; size_t spillLanes = 0;
   bool packedQueue = true; // TWK_PACKED_QUEUE=0: A/B
-  bool shadeSort = true;   // TWK_SHADE_SORT=0: A/B
+  int shadeSort = 1;       // TWK_SHADE_SORT=0: slot order (A/B); 1: class order in every launch but the first of a pass; 2: in the first too
   float4* d_firstHit = nullptr; int* d_firstHitInstance = nullptr;
   // denoiser AOVs (Optix7Gui raygeneration.cu:125-164): per-path values of a pass and their running means per launch index
   bool aovEnabled = false; int shaderVariant = TWK_SHADERS_RTIGO3;
@@ -287,7 +287,7 @@ static void refreshParams(TwkDevice dev)
   // the time view runs the measurement builds of the kernels, which tally: into a scratch block unless statistics are on
   p.stats = dev->statsEnabled ? dev->d_stats : (dev->timeView ? dev->d_stats + TWK_STATS_WORDS / 2 : nullptr);
   p.pathTime = dev->timeView ? dev->d_pathTime : nullptr; p.clockScale = dev->state.clockFactor * 1.0e-9f; // Device.h:350 CLOCK_FACTOR_SCALE
-  p.shaderVariant = dev->shaderVariant; p.shadeSort = dev->shadeSort ? 1 : 0;
+  p.shaderVariant = dev->shaderVariant; p.shadeSort = dev->shadeSort;
   p.nextEventEstimation = dev->nextEventEstimation ? 1 : 0; p.debugExceptions = dev->debugExceptions ? 1 : 0;
   p.pathAlbedo = dev->aovEnabled ? dev->d_pathAlbedo : nullptr; p.pathNormal = dev->aovEnabled ? dev->d_pathNormal : nullptr;
   p.aovAlbedo  = dev->aovEnabled ? dev->d_aovAlbedo : nullptr;  p.aovNormal  = dev->aovEnabled ? dev->d_aovNormal : nullptr;
@@ -761,7 +761,7 @@ try
   if (const char* e = getenv("TWK_TILE_ENTRIES")) dev->tileEntries = (atoi(e) != 0);
   if (const char* e = getenv("TWK_WIDE_ROOT")) dev->wideRoot = (atoi(e) != 0);
   if (const char* e = getenv("TWK_PACKED_QUEUE")) dev->packedQueue = (atoi(e) != 0);
-  if (const char* e = getenv("TWK_SHADE_SORT")) dev->shadeSort = (atoi(e) != 0);
+  if (const char* e = getenv("TWK_SHADE_SORT")) dev->shadeSort = atoi(e);
   if (const char* e = getenv("TWK_TRACE_WAVES_RUNTIME")) dev->traceWavesForced = atoi(e); // A/B: 6 or 7 blocks per CU of the persistent trace kernel
   if (const char* e = getenv("TWK_BUILD_QUALITY")) dev->builder.setQuality(atoi(e)); // A/B: 0 LBVH, 1 binned SAH (default)
   memset(&dev->buildInfo, 0, sizeof(dev->buildInfo));

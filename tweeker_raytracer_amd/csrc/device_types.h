@@ -203,7 +203,7 @@ struct LaunchParams
   float4* aovAlbedo;      // their running means per launch index (raygeneration.cu:239-262)
   float4* aovNormal;
   int     shaderVariant;  // TWK_SHADERS_RTIGO3 / TWK_SHADERS_OPTIX7GUI (include/tweeker_hip.h)
-  int     shadeSort;      // 1: shadeKernel shades the slots of a block's window in class order (shade_kernels.hip "class-coherent execution"); TWK_SHADE_SORT=0: slot order
+  int     shadeSort;      // shadeKernel shades the slots of a block's window in class order (shade_kernels.hip "class-coherent execution"): 1 = in every launch but the first of a pass (default), 2 = in the first too, 0 = slot order (TWK_SHADE_SORT)
   int     nextEventEstimation; // ≙ USE_NEXT_EVENT_ESTIMATION (shaders/config.h:50-52), a run-time switch here (twk_set_next_event_estimation): 0 = brute-force path tracing, no light sampling, no MIS weights
   int     debugExceptions;     // ≙ USE_DEBUG_EXCEPTIONS (config.h:54-56; raygeneration.cu:205-218): NaN / Inf / negative samples become super red / green / blue instead of NaN being dropped
   int     outputFrame;    // 1: `output` is a shared full W x H frame addressed by absolute pixel (ZeroCopy / PeerAccess strategies), 0: this device's packed launchWidth x H buffer

@@ -6,6 +6,9 @@
 // Per-path RNG draw order is the reference's: jitter rng2; per bounce the BSDF's draws, then NEE rng2
 // [+ rng when more than one light], then Russian roulette rng.
 #pragma once
+#ifndef TWK_PROBE_GGX_AS_LAMBERT
+#define TWK_PROBE_GGX_AS_LAMBERT 0
+#endif
 #include "device_types.h"
 
 namespace twk {
@@ -287,7 +290,11 @@ TWK_D float distribution_G(const float ax, const float ay, const V3& wo, const V
 template<bool MEASURE = false>
 TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, PathPrd& prd, unsigned int* phaseLds = nullptr)
 {
+#if TWK_PROBE_GGX_AS_LAMBERT // timing probe (wrong image): what the kernel costs without its rare expensive class
+  switch (material.indexBSDF == 3 ? 0 : material.indexBSDF)
+#else
   switch (material.indexBSDF)
+#endif
   {
     default:
     case 0: // bxdf_diffuse.cu:67-86
@@ -382,7 +389,11 @@ TWK_D void sampleBsdf(const DevMaterial& material, const SurfaceState& state, Pa
 // Eval callables (closesthit.cu:271): f in xyz, pdf in w.
 TWK_D float4 evalBsdf(const DevMaterial& material, const SurfaceState& state, const PathPrd& prd, const V3& wiL)
 {
+#if TWK_PROBE_GGX_AS_LAMBERT
+  if (material.indexBSDF == 0 || material.indexBSDF == 3)
+#else
   if (material.indexBSDF == 0) // bxdf_diffuse.cu:89-96
+#endif
   {
     const V3 f = state.albedo * kInvPi;
     const float pdf = fmaxf(0.0f, dot(wiL, state.normal) * kInvPi);
@@ -627,7 +638,11 @@ TWK_D void shadePath(const LaunchParams& p, const ShadeTables& tables, int depth
     const float4* sv = p.shadeTriangles + TWK_SHADE_RECORD * (size_t) __float_as_int(hit.w);
     const float4 s0 = sv[0], s1 = sv[1], s2 = sv[2];
     const DevMaterial& material = tables.materials[inst.material];
+#if TWK_PROBE_GGX_AS_LAMBERT
+    const bool needTangent  = material.indexBSDF >= 4;
+#else
     const bool needTangent  = material.indexBSDF >= 3;
+#endif
     const bool needTexcoord = TEX && material.textureAlbedo != 0;
 
     const float beta = hit.y, gamma = hit.z;

@@ -142,15 +142,17 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 #endif
 static_assert(TWK_SHADE_BLOCK == 256, "the class sort's places are 8 bits");
 
-// order of the classes in a sorted window: the two that sample lights (Lambert, GGX reflection) side by side
+// Order of the classes in a sorted window: Lambert, the class with most lanes, in front; GGX, the rare expensive one (its wave
+// takes 2.4 x a Lambert wave's cycles on C2 and is what a block iteration waits for), at the end next to the classes that end the
+// path or only reflect. (Measured against the order miss, light, mirror, glass, rough glass, Lambert, GGX: no difference.)
 TWK_D unsigned int shadeClass(const ShadeTables& tables, int instanceIndex, bool active)
 {
   if (!active) return 7u;                           // beyond the queue, or an inactive launch index
-  if (instanceIndex < 0) return 0u;                 // miss program
+  if (instanceIndex < 0) return 3u;                 // miss program
   const DevInstance& inst = tables.instances[instanceIndex];
-  if (inst.light >= 0) return 1u;                   // light geometry
+  if (inst.light >= 0) return 4u;                   // light geometry
   const int bsdf = tables.materials[inst.material].indexBSDF;
-  return (bsdf == 1) ? 2u : (bsdf == 2) ? 3u : (bsdf == 4) ? 4u : (bsdf == 3) ? 6u : 5u; // mirror, glass, rough glass, GGX; Lambert (default)
+  return (bsdf == 1) ? 2u : (bsdf == 2) ? 1u : (bsdf == 4) ? 5u : (bsdf == 3) ? 6u : 0u; // mirror, glass, rough glass, GGX; Lambert (default)
 }
 // What a thread hands over: the streams of one queue slot as loaded (ShadeInput), 80 bytes, as four 16-byte rows + four words.
 struct ShadeExchange
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   if (MEASURE) { if (threadIdx.x < 3 * TWK_SHADE_PHASES) phaseWords[threadIdx.x] = 0u; __syncthreads(); }
   const bool measurePhases = MEASURE && p.stats != nullptr; // time view alone: only the path time
   constexpr bool EXCHANGE = LDS_TABLES && (SORT || MEASURE);
-  const bool sorted = LDS_TABLES && (MEASURE ? (p.shadeSort != 0) : SORT);
+  const bool sorted = LDS_TABLES && (MEASURE ? (p.shadeSort == 2 || (p.shadeSort == 1 && !PRIMARY)) : SORT); // as launchShade chooses for the plain builds
   __shared__ __attribute__((aligned(16))) unsigned int classCount[TWK_SHADE_CLASSES]; // class sort: threads of the window per class (zero between uses)
   __shared__ float4 exchangeStorage[EXCHANGE ? sizeof(ShadeExchange) / 16 : 1];
   if (EXCHANGE && threadIdx.x < TWK_SHADE_CLASSES) classCount[threadIdx.x] = 0u; // the table copy's barrier is behind this
@@ -580,7 +582,7 @@ void launchShade(const LaunchParams& p, int depth, bool primary, int gridBlocks,
     else         { if (ldsSort) launchShadeVariant<false, true, true, false>(p, depth, gridBlocks, stream); else launchShadeVariant<false, false, true, false>(p, depth, gridBlocks, stream); }
     return;
   }
-  if (p.shadeSort && ldsSort)
+  if (p.shadeSort && ldsSort && !(p.shadeSort == 1 && primary)) // the first launch of a pass: neighbouring pixels hit alike, the sort only costs (shade -2.5 %); TWK_SHADE_SORT=2 sorts it too
   {
     if (primary) launchShadeVariant<true, true, false, true>(p, depth, gridBlocks, stream); else launchShadeVariant<false, true, false, true>(p, depth, gridBlocks, stream);
     return;
