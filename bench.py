@@ -402,10 +402,10 @@ def main():
                        "sample_ggx_glass", "nee_sample", "nee_eval", "radiance_rmw", "tail", "volume_push", "aov", "kernel_load", "kernel_append", "kernel_iteration"]
         shade_ms, shade_launches = prof["shade"]["ms"], max(1, prof["shade"]["launches"])
         shade_block = {
-            "kernel": "twk::shadeKernel<ENV, TEX, PRIMARY, LDS_TABLES, MEASURE>",
+            "kernel": "twk::shadeKernel<ENV, TEX, PRIMARY, LDS_TABLES, MEASURE, SORT>",
             "ms_per_step": shade_ms / args.steps, "launches": shade_launches,
             "segments_per_step": (st["shadedHits"] + st["missed"]) / args.steps,
-            "bound": "at three limits at once (profiles/r05_shade_diagnosis.md): vector issue (busy ~1.0), the HBM rate of its three big launches, the launch and fetch-chain floors of the small ones",
+            "bound": "the latency of a block iteration at 20 resident waves per CU (profiles/r05_shade_diagnosis.md 7-8): its slowest wave (the GGX class, exact arithmetic), two barriers and a returning atomic; 1.2 x above the 0.16 ms per step its compulsory streams take at 4.2 TB/s. Until round 5: the returning atomic on ONE counter word (87.8 per microsecond)",
             "valu_issue_ratio_4_clock_model_pmc": spmc.get("valu_issue_ratio_uncapped_4_clock_model") if spmc else None,
             "valu_lane_utilisation_pmc": spmc.get("valu_lane_utilisation") if spmc else None,
             "hbm_side_gbps_pmc": (spmc["hbm_bytes_per_launch"] / (shade_ms * 1.0e-3 / shade_launches) / 1.0e9) if spmc else None,
