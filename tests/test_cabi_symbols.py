@@ -87,9 +87,10 @@ def test_bench_carries_pmc_traffic_only_for_the_matching_launch_size():
     assert rec is not None and name == "r05_trace_hbm_traffic_s20.json" and rec["steps"] == 20 and rec["hbm_bytes_per_launch"] > 1e9
     rec64, name64 = bench.pick_pmc_record(64, 64, (1920, 1080))
     assert rec64 is not None and name64 == "r05_trace_hbm_traffic_s64.json" and rec64["hbm_bytes_per_launch"] > 2.5 * rec["hbm_bytes_per_launch"]
-    # the shade kernel has records of its own (roofline.shade), and they carry the uncapped issue ratio
+    # the shade kernel has records of its own (roofline.shade), and they carry the uncapped issue ratio; since the class-ordered
+    # windows (round 5) more than half of the lanes are active per vector instruction (the review's threshold: 0.55; 0.37 before)
     shade, shade_name = bench.pick_pmc_record(20, 20, (1920, 1080), kernel="shade")
-    assert shade is not None and shade_name == "r05_shade_hbm_traffic_s20.json" and shade["valu_issue_ratio_uncapped_4_clock_model"] > 0.9 and shade["valu_lane_utilisation"] < 0.5
+    assert shade is not None and shade_name == "r05_shade_hbm_traffic_s20.json" and shade["valu_issue_ratio_uncapped_4_clock_model"] > 0.5 and shade["valu_lane_utilisation"] >= 0.55
     big, _ = bench.pick_pmc_record(32, 32, (1920, 1080), 2800)
     assert big is not None and big["sphere_tess"] == 2800 and big["l2_hit_rate"] < 0.5
     none, why = bench.pick_pmc_record(7, 7, (1920, 1080))
