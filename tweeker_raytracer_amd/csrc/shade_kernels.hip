@@ -140,7 +140,7 @@ TWK_D void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 #ifndef TWK_SHADE_SORT_TABLE_BYTES
 #define TWK_SHADE_SORT_TABLE_BYTES 8192 // table budget of the builds that carry the exchange buffer (20 KiB): five blocks per CU = 145 of 160 KiB
 #endif
-static_assert(TWK_SHADE_BLOCK == 256, "the class sort's places are 8 bits");
+static_assert((TWK_SHADE_BLOCK & (TWK_SHADE_BLOCK - 1)) == 0, "the sorted window wraps with a mask");
 
 // Order of the classes in a sorted window: Lambert, the class with most lanes, in front; GGX, the rare expensive one (its wave
 // takes 2.4 x a Lambert wave's cycles on C2 and is what a block iteration waits for), at the end next to the classes that end the
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   if (blockIdx.x * blockDim.x >= numRays) return;
   const int q = depth & 1, qn = q ^ 1;
   const bool packedIn = p.packedQueue != 0 && depth > 0, packedOut = p.packedQueue != 0; // queue 0 is computed (PRIMARY) or written by generateKernel
-  ShadeInput in;
+  ShadeInput in = {}; // a thread beyond the queue hands its (empty) record to the exchange all the same
   loadShadeInput<PRIMARY>(p, q, blockIdx.x * blockDim.x + threadIdx.x, segments, packedIn, in);
 
   __shared__ unsigned int waveCount[2][2][TWK_SHADE_BLOCK / 64];
