@@ -268,9 +268,10 @@ __global__ void __launch_bounds__(TWK_SHADE_BLOCK, ENV ? TWK_SHADE_WAVES_ENV : (
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
-  // The kernel is bound by its chain of dependent fetches, not by arithmetic, so the chain is kept
-  // short: the streams of the NEXT iteration's slot are requested between the two barriers of the append — they fly
-  // while the block waits for its returning atomic — and nothing waits for the appended records to be written.
+  // A block iteration is a chain of waits — the slot's streams, the shading record, the slowest wave at the
+  // append's first barrier, the returning atomic — so the chain is kept short: the streams of the NEXT iteration's slot are
+  // requested between the two barriers of the append — they fly while the block waits for its returning atomic — and nothing
+  // waits for the appended records to be written.
   unsigned int buffer = 0u;
 
   // block-uniform trip count: every thread reaches both barriers of every iteration
