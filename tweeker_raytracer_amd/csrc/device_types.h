@@ -323,7 +323,7 @@ TWK_HD unsigned int physicalSlot(const QueueSegments& s, unsigned int stride, un
 #endif
 // Passes of at most this many paths are cut into two lanes (device_api.hip chooseLanes); measured on C2, DESIGN.md 2.
 #ifndef TWK_LANES2_MAX_PATHS
-#define TWK_LANES2_MAX_PATHS 30000000 // passes of at most this many paths run as two lanes (round 3: 9 M; re-measured on the round's final kernels: +0.9 % at 20.7 M paths of C2, +1.6 % on a C5 rank's share of 20 iterations, a tie at 29 M, -2 % at 41 M)
+#define TWK_LANES2_MAX_PATHS 21000000 // passes of at most this many paths run as two lanes. Round 5's final kernels, C2, one against two lanes: 2.1 M paths 1 138 / 1 211 Msamples/s, 4.1 M 1 646 / 1 735, 10.4 M 2 304 / 2 375, 20.7 M 2 760 / 2 766, 29 M 2 962 / 2 863 (a C5 rank's share of 20 iterations, 20.7 M: 2 746 / 2 718). Until then 30 M
 #endif
 #ifndef TWK_TRACE_SMALL_CHUNK
 #define TWK_TRACE_SMALL_CHUNK 64   // queue slots per chunk of a SHORT queue (fewer than TWK_TRACE_TAIL_MIN long chunks per wave), 0 = round 2's one contiguous share per wave
