@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 ARGS="--steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-roofline $*"
-# one lane for every pass: a warm-up pass of <= 30 M paths would run as two lanes (twice the dispatches of the timed pass), and
+# one lane for every pass: a warm-up pass of <= 21 M paths would run as two lanes (twice the dispatches of the timed pass), and
 # tools/pmc_traffic.py finds the timed pass's dispatches by position; the timed passes of both launch sizes are one lane anyway
 export TWK_PASS_LANES=1
 echo "$STEPS $WARMUP" > $OUT/steps_warmup.txt
